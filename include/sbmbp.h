@@ -1,0 +1,175 @@
+/*
+ * sbmbp.h — C ABI of the MI355X-native belief-propagation engine for the (degree-corrected)
+ * stochastic block model. This is the drop-in boundary for the reference's BP path: every entry
+ * point names the reference interface (file:line under junipertcy/sbm-bp `src/`) it replaces.
+ *
+ * The reference has no FFI layer; its de-facto source-level boundary is the public interface of
+ * `class belief_propagation` as `main.cpp:318-365` drives it (belief_propagation.h:96-142), plus
+ * `blockmodel.h:105-107` (parameter constructors) and `graph_utilities.h:14-22` (graph input).
+ * A maintainer binds these functions from `main.cpp` as shown in INTEGRATION.md.
+ *
+ * Conventions: plain C types only; 0 = SBMBP_OK, negative = error (sbmbp_strerror);
+ * the caller owns every host array it passes (the library copies); the library owns all device
+ * memory; one engine handle = one GPU = one host thread; no exceptions cross the boundary.
+ * All floating-point state is IEEE double, as in the reference (types.h:38-41).
+ *
+ * Data layout (HBM): CSR rows = vertices, neighbours ascending (== std::set order of
+ * types.h:14-15); rev[k] = index of the reverse directed edge; messages are OUT-ordered AoS:
+ * msg[k*Q+q] = message from row(k) to nbr[k]. The reference's in-ordered mmap_[i][l][q]
+ * (belief_propagation.h:65-66) is msg[rev[row_ptr[i]+l]*Q+q].
+ */
+#ifndef SBMBP_H
+#define SBMBP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBMBP_OK 0
+#define SBMBP_ERR_ARG (-1)         /* invalid argument / shape mismatch */
+#define SBMBP_ERR_HIP (-2)         /* a HIP runtime call failed (detail in sbmbp_last_error) */
+#define SBMBP_ERR_NODEVICE (-3)    /* no usable GPU: the engine never falls back to the CPU */
+#define SBMBP_ERR_STATE (-4)       /* call order violated (e.g. converge before set_params) */
+#define SBMBP_ERR_IO (-5)          /* file could not be read */
+#define SBMBP_ERR_UNSUPPORTED (-6) /* e.g. Q above SBMBP_MAX_Q */
+#define SBMBP_ERR_NOMEM (-7)
+
+#define SBMBP_MAX_Q 8 /* label count handled by the templated kernels */
+
+typedef struct sbmbp_graph sbmbp_graph_t;   /* host-side CSR graph */
+typedef struct sbmbp_engine sbmbp_engine_t; /* device engine (one GPU) */
+
+const char *sbmbp_strerror(int code);
+const char *sbmbp_last_error(void); /* thread-local detail string of the last failure */
+const char *sbmbp_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Graph input. Replaces load_edge_list + edge_to_adj (graph_utilities.cpp:42-77: text "a b" per
+ * line, symmetrised, de-duplicated, neighbours sorted, vertex count grown to the largest id) and
+ * the graph_neis_/graph_neis_inv_ build of bp_allocate (belief_propagation.cpp:246-266).
+ * Deviation (documented): a missing file is an error here, not an empty graph.
+ * ------------------------------------------------------------------------------------------- */
+int sbmbp_graph_load_edgelist(sbmbp_graph_t **out, const char *path, uint32_t n_vertices);
+int sbmbp_graph_from_edges(sbmbp_graph_t **out, const uint32_t *pairs /* [2*n_pairs] */, uint64_t n_pairs,
+                           uint32_t n_vertices);
+/* adopt an existing CSR (rev may be NULL: it is then computed). Arrays are copied and validated. */
+int sbmbp_graph_from_csr(sbmbp_graph_t **out, uint32_t n_vertices, uint64_t n_directed,
+                         const uint64_t *row_ptr, const uint32_t *nbr, const uint32_t *rev);
+uint32_t sbmbp_graph_num_vertices(const sbmbp_graph_t *g);
+uint64_t sbmbp_graph_num_directed_edges(const sbmbp_graph_t *g); /* E2 = 2|E| */
+uint32_t sbmbp_graph_max_degree(const sbmbp_graph_t *g);         /* blockmodel_t::get_graph_max_degree, blockmodel.cpp:51 */
+int sbmbp_graph_copy_csr(const sbmbp_graph_t *g, uint64_t *row_ptr, uint32_t *nbr, uint32_t *rev);
+void sbmbp_graph_destroy(sbmbp_graph_t *g);
+
+/* ---------------------------------------------------------------------------------------------
+ * Model parameters. Replace bp_param_from_epsilon_c (blockmodel.cpp:229-272) and
+ * bp_param_from_direct (blockmodel.cpp:274-302) incl. the na[q]=unsigned(int(pa[q]*N)) truncation.
+ * cab is Q*Q row-major; cab_upper is the upper triangle, row-major, as `--cab` passes it.
+ * ------------------------------------------------------------------------------------------- */
+int sbmbp_param_from_epsilon_c(uint32_t n_vertices, uint32_t Q, double epsilon, double c, double *cab, uint32_t *na);
+int sbmbp_param_from_direct(uint32_t n_vertices, uint32_t Q, const double *pa, const double *cab_upper,
+                            double *cab, uint32_t *na);
+
+/* ---------------------------------------------------------------------------------------------
+ * Engine life cycle. sbmbp_create replaces bp_allocate (belief_propagation.cpp:223-288): it
+ * uploads the CSR and allocates messages/marginals in HBM. device < 0 selects the current device.
+ * ------------------------------------------------------------------------------------------- */
+int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint32_t deg_corr_flag, int device);
+void sbmbp_destroy(sbmbp_engine_t *e);
+/* run all work of this engine on an existing HIP stream (hipStream_t passed as void*); NULL = own stream */
+int sbmbp_set_stream(sbmbp_engine_t *e, void *hip_stream);
+
+/* init_messages (belief_propagation.cpp:101-217): same std::mt19937(seed) stream and fill order as
+ * the reference for flag 0/1 (per vertex: psi, then its out-messages in ascending neighbour
+ * order). conf: N entries, -1 = unknown, may be NULL for flag 0. true_conf: N entries.
+ * conditional != 0 selects bp_conditional semantics (rows with conf != -1 are clamped,
+ * belief_propagation.cpp:1100-1126); 0 selects bp_basic. Flags 2/3: see DESIGN.md (reference
+ * asserts). */
+int sbmbp_init_messages(sbmbp_engine_t *e, uint32_t flag, const int32_t *conf, const uint32_t *true_conf,
+                        uint32_t seed, int conditional);
+/* device-side random initialisation (counter-based generator) for large synthetic runs where the
+ * sequential mt19937 fill would dominate; not stream-compatible with the reference. */
+int sbmbp_init_messages_device(sbmbp_engine_t *e, uint64_t seed, const uint32_t *true_conf);
+
+/* expand_bp_params + set_beta (belief_propagation.cpp:290-317, 417-419) */
+int sbmbp_set_params(sbmbp_engine_t *e, const double *cab, const uint32_t *na, double beta);
+int sbmbp_get_params(sbmbp_engine_t *e, double *cab, uint32_t *na);
+
+/* direct state access (the reference keeps real_psi_/mmap_ protected, belief_propagation.h:45,66) */
+int sbmbp_set_state(sbmbp_engine_t *e, const double *psi /* N*Q or NULL */, const double *msg_out /* E2*Q or NULL */);
+int sbmbp_get_state(sbmbp_engine_t *e, double *psi /* or NULL */, double *msg_out /* or NULL */);
+int sbmbp_get_field(sbmbp_engine_t *e, double *h /* Q */); /* h_ of belief_propagation.cpp:320-360 */
+
+/* Schedule of the synchronous sweep (no reference counterpart: the reference is random-sequential,
+ * belief_propagation.cpp:394-401). field_mix in (0,1]: relaxation of the global field between
+ * sweeps (1 = plain Jacobi). check_every >= 1: sweeps enqueued between two host reads of the
+ * convergence flag (the returned niter is exact regardless). */
+int sbmbp_set_schedule(sbmbp_engine_t *e, double field_mix, uint32_t check_every);
+
+/* converge (belief_propagation.cpp:386-415): returns in *niter the 0-based index of the first sweep
+ * whose max |delta message| < crit, or -1 after max_sweeps. damping == dumping_rate. */
+int sbmbp_converge(sbmbp_engine_t *e, double crit, uint32_t max_sweeps, double damping, int *niter,
+                   double *last_maxdiff);
+/* exactly n_sweeps synchronous sweeps, no convergence test (benchmarking / stepping) */
+int sbmbp_sweep(sbmbp_engine_t *e, double damping, uint32_t n_sweeps, double *last_maxdiff);
+
+/* compute_free_energy (belief_propagation.cpp:744-750) = -f_site + f_edge + f_nonedge;
+ * parts = {f_site, f_edge, f_nonedge} (:442-504, :562-612, :675-709). The non-edge term is exact
+ * (tiled N^2 kernel) for N <= the exact limit, else the moment series of DESIGN.md. */
+int sbmbp_free_energy(sbmbp_engine_t *e, double *f, double *parts /* 3 or NULL */);
+/* compute_entropy (belief_propagation.cpp:752-758); NaN for deg_corr_flag != 0 as the reference */
+int sbmbp_entropy(sbmbp_engine_t *e, double *entropy, double *parts /* 3 or NULL */);
+/* nonedge_mode: 0 = automatic, 1 = force exact N^2, 2 = force series; series_order 0 = automatic */
+int sbmbp_set_nonedge_mode(sbmbp_engine_t *e, int nonedge_mode, int series_order);
+
+/* compute_na_expect + compute_cab_expect (belief_propagation.cpp:428-440, 892-989) */
+int sbmbp_em_expectations(sbmbp_engine_t *e, double *na_expect, double *nna_expect, double *cab_expect);
+/* confusion matrix C[a*Q+b] = sum_{i: true_i = a} psi_i[b] and compute_overlap (:775-811) */
+int sbmbp_confusion(sbmbp_engine_t *e, double *C);
+int sbmbp_overlap(sbmbp_engine_t *e, double *overlap);
+
+/* inference (belief_propagation.cpp:77-99): converge, free energy, entropy, overlap */
+typedef struct sbmbp_infer_result {
+    double entropy, free_energy, overlap;
+    int niter;
+    double last_maxdiff;
+} sbmbp_infer_result;
+int sbmbp_inference(sbmbp_engine_t *e, float conv_crit, uint32_t time_conv, float dumping_rate,
+                    sbmbp_infer_result *out);
+
+/* learning + learning_step (belief_propagation.cpp:14-75): EM loop with the reference's stopping
+ * rule (criterion shrinks by 0.1 whenever fdiff falls below it; -e is not used).
+ * On return eta/cab hold what the reference prints (:48-49). status: 0 = ran out of steps,
+ * 1 = "fdiff < learning_conv_crit", 2 = free energy became NaN/Inf. */
+typedef struct sbmbp_learn_result {
+    int em_steps;
+    int status;
+    double free_energy;
+    double overlap;
+    uint64_t total_sweeps;
+} sbmbp_learn_result;
+int sbmbp_learning(sbmbp_engine_t *e, float learning_conv_crit, uint32_t learning_max_time, float learning_rate,
+                   float dumping_rate, sbmbp_learn_result *out);
+
+/* counters for the metric "BP edge-message updates per second" */
+typedef struct sbmbp_stats {
+    uint64_t sweeps;             /* synchronous sweeps executed so far */
+    uint64_t edge_msg_updates;   /* sweeps * E2 */
+    double sweep_kernel_ms;      /* HIP-event time of the sweep kernels (sum) on the engine's stream */
+    uint64_t sweep_launches;     /* number of sweep-kernel launches timed */
+    double bytes_per_sweep;      /* algorithmic bytes of one sweep */
+    uint64_t device_bytes;       /* HBM held by this engine */
+    uint32_t n_blocks;           /* workgroups of one sweep launch */
+    uint32_t n_hub_rows;         /* rows handled by the workgroup-per-row kernel */
+} sbmbp_stats;
+int sbmbp_get_stats(sbmbp_engine_t *e, sbmbp_stats *out);
+int sbmbp_reset_stats(sbmbp_engine_t *e);
+/* when on, every sweep launch is bracketed by HIP events on the engine's stream (bench.py) */
+int sbmbp_set_timing(sbmbp_engine_t *e, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBMBP_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of the C ABI declared in include/sbmbp.h. Fails loudly when the HIP library is
+missing — there is no fallback implementation behind these symbols."""
+import ctypes as C
+import os
+
+from sbm_bp_amd.build import lib_path
+
+c_dp = C.POINTER(C.c_double)
+c_u32p = C.POINTER(C.c_uint32)
+c_u64p = C.POINTER(C.c_uint64)
+c_i32p = C.POINTER(C.c_int32)
+
+
+class SbmbpError(RuntimeError):
+    def __init__(self, code, what, detail):
+        super().__init__("sbmbp: %s (code %d)%s" % (what, code, (": " + detail) if detail else ""))
+        self.code = code
+
+
+class InferResult(C.Structure):
+    _fields_ = [("entropy", C.c_double), ("free_energy", C.c_double), ("overlap", C.c_double),
+                ("niter", C.c_int), ("last_maxdiff", C.c_double)]
+
+
+class LearnResult(C.Structure):
+    _fields_ = [("em_steps", C.c_int), ("status", C.c_int), ("free_energy", C.c_double), ("overlap", C.c_double),
+                ("total_sweeps", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("sweeps", C.c_uint64), ("edge_msg_updates", C.c_uint64), ("sweep_kernel_ms", C.c_double),
+                ("sweep_launches", C.c_uint64), ("bytes_per_sweep", C.c_double), ("device_bytes", C.c_uint64),
+                ("n_blocks", C.c_uint32), ("n_hub_rows", C.c_uint32)]
+
+
+# every symbol include/sbmbp.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "sbmbp_strerror": (C.c_char_p, [C.c_int]),
+    "sbmbp_last_error": (C.c_char_p, []),
+    "sbmbp_version": (C.c_char_p, []),
+    "sbmbp_graph_load_edgelist": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_uint32]),
+    "sbmbp_graph_from_edges": (C.c_int, [C.POINTER(C.c_void_p), c_u32p, C.c_uint64, C.c_uint32]),
+    "sbmbp_graph_from_csr": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint64, c_u64p, c_u32p, c_u32p]),
+    "sbmbp_graph_num_vertices": (C.c_uint32, [C.c_void_p]),
+    "sbmbp_graph_num_directed_edges": (C.c_uint64, [C.c_void_p]),
+    "sbmbp_graph_max_degree": (C.c_uint32, [C.c_void_p]),
+    "sbmbp_graph_copy_csr": (C.c_int, [C.c_void_p, c_u64p, c_u32p, c_u32p]),
+    "sbmbp_graph_destroy": (None, [C.c_void_p]),
+    "sbmbp_param_from_epsilon_c": (C.c_int, [C.c_uint32, C.c_uint32, C.c_double, C.c_double, c_dp, c_u32p]),
+    "sbmbp_param_from_direct": (C.c_int, [C.c_uint32, C.c_uint32, c_dp, c_dp, c_dp, c_u32p]),
+    "sbmbp_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]),
+    "sbmbp_destroy": (None, [C.c_void_p]),
+    "sbmbp_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sbmbp_init_messages": (C.c_int, [C.c_void_p, C.c_uint32, c_i32p, c_u32p, C.c_uint32, C.c_int]),
+    "sbmbp_init_messages_device": (C.c_int, [C.c_void_p, C.c_uint64, c_u32p]),
+    "sbmbp_set_params": (C.c_int, [C.c_void_p, c_dp, c_u32p, C.c_double]),
+    "sbmbp_get_params": (C.c_int, [C.c_void_p, c_dp, c_u32p]),
+    "sbmbp_set_state": (C.c_int, [C.c_void_p, c_dp, c_dp]),
+    "sbmbp_get_state": (C.c_int, [C.c_void_p, c_dp, c_dp]),
+    "sbmbp_get_field": (C.c_int, [C.c_void_p, c_dp]),
+    "sbmbp_set_schedule": (C.c_int, [C.c_void_p, C.c_double, C.c_uint32]),
+    "sbmbp_converge": (C.c_int, [C.c_void_p, C.c_double, C.c_uint32, C.c_double, C.POINTER(C.c_int), c_dp]),
+    "sbmbp_sweep": (C.c_int, [C.c_void_p, C.c_double, C.c_uint32, c_dp]),
+    "sbmbp_free_energy": (C.c_int, [C.c_void_p, c_dp, c_dp]),
+    "sbmbp_entropy": (C.c_int, [C.c_void_p, c_dp, c_dp]),
+    "sbmbp_set_nonedge_mode": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "sbmbp_em_expectations": (C.c_int, [C.c_void_p, c_dp, c_dp, c_dp]),
+    "sbmbp_confusion": (C.c_int, [C.c_void_p, c_dp]),
+    "sbmbp_overlap": (C.c_int, [C.c_void_p, c_dp]),
+    "sbmbp_inference": (C.c_int, [C.c_void_p, C.c_float, C.c_uint32, C.c_float, C.POINTER(InferResult)]),
+    "sbmbp_learning": (C.c_int, [C.c_void_p, C.c_float, C.c_uint32, C.c_float, C.c_float, C.POINTER(LearnResult)]),
+    "sbmbp_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "sbmbp_reset_stats": (C.c_int, [C.c_void_p]),
+    "sbmbp_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+}
+
+_LIB = None
+
+
+def load_library():
+    """dlopen csrc/libsbmbp_hip.so (built in-tree by sbm_bp_amd.build) and type every entry point."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise SbmbpError(-3, "native library missing", path + " (run __graft_entry__.build(); there is no CPU fallback)")
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError = symbol missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        lib = load_library()
+        raise SbmbpError(code, lib.sbmbp_strerror(code).decode(), lib.sbmbp_last_error().decode())

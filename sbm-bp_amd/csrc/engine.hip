@@ -1,0 +1,924 @@
+// Device engine + C ABI (include/sbmbp.h). Host logic is C++14; kernels are in kernels.h.
+// There is no CPU fallback anywhere in this file: without a GPU sbmbp_create fails with
+// SBMBP_ERR_NODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/sbmbp.h"
+#include "host_graph.h"
+#include "kernels.h"
+
+using namespace sbmbp;
+
+#define HIPCHK(call)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (call);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            set_error(std::string(#call) + ": " + hipGetErrorString(_e));                     \
+            return SBMBP_ERR_HIP;                                                             \
+        }                                                                                     \
+    } while (0)
+
+#define CHK(call)                  \
+    do {                           \
+        int _r = (call);           \
+        if (_r != SBMBP_OK) return _r; \
+    } while (0)
+
+struct sbmbp_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint32_t N = 0, Q = 0, dc = 0;
+    uint64_t E2 = 0;
+    // graph + work decomposition in HBM
+    uint32_t *d_row_ptr = nullptr, *d_rev = nullptr, *d_nbr = nullptr, *d_src = nullptr;
+    uint32_t *d_blk_row = nullptr, *d_hub_row = nullptr, *d_hub_blk = nullptr, *d_true = nullptr;
+    int32_t *d_clamp = nullptr;
+    uint32_t n_blk = 0, n_hub = 0;
+    // state in HBM
+    double *d_M[2] = {nullptr, nullptr};
+    int cur = 0;
+    double *d_psi = nullptr;
+    dev_params *d_P = nullptr;
+    double *d_partials = nullptr;
+    size_t partials_cap = 0;  // doubles
+    double *d_small = nullptr;  // folded results
+    size_t small_cap = 0;
+    double *d_hist = nullptr;
+    uint32_t hist_cap = 0;
+    double *d_mats = nullptr;  // 3 * Q*Q small matrices for the non-edge kernels
+    uint64_t device_bytes = 0;
+    // host mirrors
+    std::vector<double> cab, W;
+    std::vector<uint32_t> na;
+    std::vector<double> eta;
+    std::vector<uint32_t> true_conf;
+    std::vector<uint32_t> h_row_ptr;  // host copy of the row offsets (fill order of init_messages)
+    double beta = 1.0;
+    double sum_log_didl = 0.0;  // sum over directed edges of log(d_i d_l) (dc 1 constant of f_site/f_edge)
+    bool have_params = false, have_state = false, has_clamp = false, field_fresh = false;
+    double field_mix = 1.0;
+    uint32_t check_every = 1;
+    int nonedge_mode = 0, series_order = 0;
+    // stats
+    uint64_t sweeps = 0, sweep_launches = 0;
+    double sweep_ms = 0.0;
+    bool timing = false;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+template <typename T> int dev_alloc(sbmbp_engine *e, T **p, size_t count) {
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t r = hipMalloc(reinterpret_cast<void **>(p), bytes);
+    if (r != hipSuccess) {
+        set_error(std::string("hipMalloc(") + std::to_string(bytes) + " B): " + hipGetErrorString(r));
+        return r == hipErrorOutOfMemory ? SBMBP_ERR_NOMEM : SBMBP_ERR_HIP;
+    }
+    e->device_bytes += bytes;
+    return SBMBP_OK;
+}
+
+int ensure_partials(sbmbp_engine *e, size_t doubles) {
+    if (doubles <= e->partials_cap) return SBMBP_OK;
+    if (e->d_partials) { hipFree(e->d_partials); e->device_bytes -= e->partials_cap * 8; }
+    e->partials_cap = 0;
+    CHK(dev_alloc(e, &e->d_partials, doubles));
+    e->partials_cap = doubles;
+    return SBMBP_OK;
+}
+int ensure_small(sbmbp_engine *e, size_t doubles) {
+    if (doubles <= e->small_cap) return SBMBP_OK;
+    if (e->d_small) { hipFree(e->d_small); e->device_bytes -= e->small_cap * 8; }
+    e->small_cap = 0;
+    CHK(dev_alloc(e, &e->d_small, doubles));
+    e->small_cap = doubles;
+    return SBMBP_OK;
+}
+
+inline int frame_cap(uint32_t Q) { return BLOCK * (Q <= 2 ? 4 : 2); }
+inline int frame_rcap(uint32_t Q) { return Q <= 4 ? 2 * BLOCK : BLOCK; }
+
+// Q/dc dispatch over the templated kernels
+#define DISPATCH_Q(Qv, ...)                                             \
+    switch (Qv) {                                                       \
+        case 2: { constexpr int QQ = 2; __VA_ARGS__; } break;           \
+        case 3: { constexpr int QQ = 3; __VA_ARGS__; } break;           \
+        case 4: { constexpr int QQ = 4; __VA_ARGS__; } break;           \
+        case 5: { constexpr int QQ = 5; __VA_ARGS__; } break;           \
+        case 6: { constexpr int QQ = 6; __VA_ARGS__; } break;           \
+        case 7: { constexpr int QQ = 7; __VA_ARGS__; } break;           \
+        case 8: { constexpr int QQ = 8; __VA_ARGS__; } break;           \
+        default: set_error("unsupported Q"); return SBMBP_ERR_UNSUPPORTED; \
+    }
+
+int upload_params(sbmbp_engine *e, double crit) {
+    dev_params P;
+    std::memset(&P, 0, sizeof P);
+    const uint32_t Q = e->Q;
+    for (uint32_t a = 0; a < Q * Q; ++a) {
+        P.cab[a] = e->cab[a];
+        P.W[a] = (e->dc == 0) ? std::pow(e->cab[a], e->beta) : (e->dc == 1 ? e->cab[a] : e->cab[a] / double(e->N));
+    }
+    for (uint32_t q = 0; q < Q; ++q) {
+        P.eta[q] = e->eta[q];
+        P.logeta[q] = std::log(e->eta[q]);
+    }
+    P.beta = e->beta;
+    P.invN = 1.0 / double(e->N);
+    P.field_mix = e->field_mix;
+    P.crit = crit;
+    P.maxdiff = 0.0;
+    P.conv_iter = -1;
+    P.sweep_idx = 0;
+    P.stop = 0;
+    P.have_prev = 0;
+    HIPCHK(hipMemcpyAsync(e->d_P, &P, sizeof P, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));  // P is a stack object
+    return SBMBP_OK;
+}
+
+// h from the current psi (init_h, bp.cpp:320-332); mode 1 = converge start, 2 = exact refresh
+int launch_field(sbmbp_engine *e, int mode) {
+    const uint32_t rows_per_blk = 4096;
+    const uint32_t nb = std::max<uint32_t>(1, (e->N + rows_per_blk - 1) / rows_per_blk);
+    CHK(ensure_partials(e, size_t(nb) * (e->Q + 1)));
+    DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_psi_sum<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_psi,
+                                        e->N, rows_per_blk, int(e->dc != 0), e->d_partials));
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, e->stream, e->d_partials, nb, int(e->Q), mode, e->d_P,
+                       (double *)nullptr, 0u);
+    HIPCHK(hipGetLastError());
+    return SBMBP_OK;
+}
+
+int launch_sweep(sbmbp_engine *e, int src_buf, double damp) {
+    const double *Mold = e->d_M[src_buf];
+    double *Mnew = e->d_M[src_buf ^ 1];
+    const int32_t *clamp = e->has_clamp ? e->d_clamp : nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (e->timing) {
+        if (e->ev_used + 2 > e->ev.size()) {
+            size_t old = e->ev.size();
+            e->ev.resize(old + 256);
+            for (size_t i = old; i < e->ev.size(); ++i) HIPCHK(hipEventCreate(&e->ev[i]));
+        }
+        e0 = e->ev[e->ev_used++];
+        e1 = e->ev[e->ev_used++];
+        HIPCHK(hipEventRecord(e0, e->stream));
+    }
+    if (e->dc == 2) {
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, true>), dim3(e->n_blk), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
+                                            e->d_rev, e->d_nbr, Mold, Mnew, e->d_psi, clamp, e->d_blk_row, e->d_P,
+                                            1, damp, e->d_partials));
+    } else {
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, false>), dim3(e->n_blk), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
+                                            e->d_rev, e->d_nbr, Mold, Mnew, e->d_psi, clamp, e->d_blk_row, e->d_P,
+                                            int(e->dc), damp, e->d_partials));
+    }
+    if (e->timing) HIPCHK(hipEventRecord(e1, e->stream));
+    if (e->n_hub) {
+        if (e->dc == 2) {
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream,
+                                                e->d_row_ptr, e->d_rev, e->d_nbr, Mold, Mnew, e->d_psi, clamp,
+                                                e->d_hub_row, e->d_hub_blk, e->d_P, 1, damp, e->d_partials));
+        } else {
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, false>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream,
+                                                e->d_row_ptr, e->d_rev, e->d_nbr, Mold, Mnew, e->d_psi, clamp,
+                                                e->d_hub_row, e->d_hub_blk, e->d_P, int(e->dc), damp, e->d_partials));
+        }
+    }
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, e->stream, e->d_partials, e->n_blk, int(e->Q), 0, e->d_P,
+                       e->d_hist, e->hist_cap);
+    HIPCHK(hipGetLastError());
+    return SBMBP_OK;
+}
+
+int collect_timing(sbmbp_engine *e) {
+    for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
+        e->sweep_ms += double(ms);
+        e->sweep_launches++;
+    }
+    e->ev_used = 0;
+    return SBMBP_OK;
+}
+
+struct conv_state { double maxdiff; int conv_iter, sweep_idx, stop, have_prev; };
+
+int read_conv_state(sbmbp_engine *e, conv_state *cs) {
+    HIPCHK(hipMemcpyAsync(cs, reinterpret_cast<const char *>(e->d_P) + offsetof(dev_params, maxdiff), sizeof(conv_state),
+                          hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SBMBP_OK;
+}
+
+// run sweeps until convergence (crit >= 0) or exactly max_sweeps (crit < 0: never converges)
+int run_sweeps(sbmbp_engine *e, double crit, uint32_t max_sweeps, double damping, int *niter, double *last) {
+    if (!e->have_params || !e->have_state) { set_error("set_params and init_messages/set_state must precede converge"); return SBMBP_ERR_STATE; }
+    CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (e->Q + 1)));
+    CHK(upload_params(e, crit));
+    CHK(launch_field(e, 1));
+    CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (e->Q + 1)));
+    uint32_t done = 0;
+    conv_state cs{0.0, -1, 0, 0, 0};
+    const uint32_t batch_max = std::max<uint32_t>(1, e->check_every);
+    while (done < max_sweeps) {
+        const uint32_t batch = std::min(batch_max, max_sweeps - done);
+        for (uint32_t b = 0; b < batch; ++b) CHK(launch_sweep(e, (e->cur + int(done + b)) & 1, damping));
+        CHK(read_conv_state(e, &cs));
+        if (e->timing) CHK(collect_timing(e));
+        done += batch;
+        if (cs.stop) break;
+    }
+    const uint32_t executed = uint32_t(cs.sweep_idx);
+    e->cur = (e->cur + int(executed)) & 1;
+    e->sweeps += executed;
+    e->field_fresh = (e->field_mix >= 1.0);
+    if (niter) *niter = cs.conv_iter;
+    if (last) *last = cs.maxdiff;
+    return SBMBP_OK;
+}
+
+// fold [rows][stride] partials into d_small[0..cols) and copy to host
+int fold_to_host(sbmbp_engine *e, uint32_t rows, uint32_t cols, uint32_t stride, double *out) {
+    CHK(ensure_small(e, cols));
+    hipLaunchKernelGGL(k_fold_rows_sum, dim3(1), dim3(BLOCK), 0, e->stream, e->d_partials, rows, cols, stride, e->d_small);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, e->d_small, size_t(cols) * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SBMBP_OK;
+}
+
+int refresh_field(sbmbp_engine *e) {
+    if (!e->have_params || !e->have_state) { set_error("engine has no parameters or no state"); return SBMBP_ERR_STATE; }
+    CHK(launch_field(e, 2));
+    e->field_fresh = true;
+    return SBMBP_OK;
+}
+
+int site_edge_terms(sbmbp_engine *e, bool want_entropy, double out[4]) {
+    CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (FE_NP + 1)));
+    const double *M = e->d_M[e->cur];
+    if (e->dc == 2) {
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_frame<QQ, true>), dim3(e->n_blk), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
+                                            e->d_rev, e->d_nbr, M, e->d_blk_row, e->d_P, 1, int(want_entropy), e->d_partials));
+        if (e->n_hub)
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
+                                                e->d_rev, e->d_nbr, M, e->d_hub_row, e->d_hub_blk, e->d_P, 1,
+                                                int(want_entropy), e->d_partials));
+    } else {
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_frame<QQ, false>), dim3(e->n_blk), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
+                                            e->d_rev, e->d_nbr, M, e->d_blk_row, e->d_P, int(e->dc), int(want_entropy),
+                                            e->d_partials));
+        if (e->n_hub)
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_hub<QQ, false>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
+                                                e->d_rev, e->d_nbr, M, e->d_hub_row, e->d_hub_blk, e->d_P, int(e->dc),
+                                                int(want_entropy), e->d_partials));
+    }
+    HIPCHK(hipGetLastError());
+    return fold_to_host(e, e->n_blk, FE_NP, FE_NP + 1, out);
+}
+
+// contraction <M_k, (m_0 x ... x m_{k-1}) M_k> of SURVEY A.4 on the host (Q^2k terms)
+double contract(const double *Mk, uint32_t Q, unsigned k, const std::vector<const double *> &mats) {
+    size_t T = 1;
+    for (unsigned j = 0; j < k; ++j) T *= Q;
+    double acc = 0.0;
+    for (size_t a = 0; a < T; ++a) {
+        if (Mk[a] == 0.0) continue;
+        double row = 0.0;
+        for (size_t b = 0; b < T; ++b) {
+            double w = 1.0;
+            size_t ra = a, rb = b;
+            for (unsigned j = 0; j < k; ++j) { w *= mats[j][(ra % Q) * Q + (rb % Q)]; ra /= Q; rb /= Q; }
+            row += w * Mk[b];
+        }
+        acc += row * Mk[a];
+    }
+    return acc;
+}
+
+int choose_series_order(const sbmbp_engine *e, double wmax) {
+    if (e->series_order > 0) return std::min(e->series_order, 4);
+    // smallest K with N (wmax/N)^(K+1) / (2(K+1)) < 1e-12  (SURVEY A.4 truncation bound)
+    for (int K = 1; K <= 4; ++K) {
+        double err = double(e->N) * std::pow(wmax / double(e->N), K + 1) / (2.0 * (K + 1));
+        if (err < 1e-12) return K;
+    }
+    return 4;
+}
+
+// non-edge terms: out[0] = f_nonedge, out[1] = e_nonedge (if want_entropy)   (bp.cpp:675-741)
+int nonedge_terms(sbmbp_engine *e, bool want_entropy, double out[2]) {
+    out[0] = out[1] = 0.0;
+    if (e->dc != 0) return SBMBP_OK;  // exactly 0 in the reference (:687-700, :721-727)
+    const uint32_t Q = e->Q, N = e->N;
+    const double invN = 1.0 / double(N);
+    std::vector<double> mats(3 * Q * Q);
+    double *wmat = mats.data(), *Pmat = mats.data() + Q * Q, *cabm = mats.data() + 2 * Q * Q;
+    double wmax = 0.0;
+    for (uint32_t a = 0; a < Q * Q; ++a) {
+        Pmat[a] = std::pow(1.0 - e->cab[a] / double(N), e->beta);
+        wmat[a] = double(N) * (1.0 - Pmat[a]);
+        cabm[a] = e->cab[a];
+        wmax = std::max(wmax, std::max(wmat[a], cabm[a]));
+    }
+    HIPCHK(hipMemcpyAsync(e->d_mats, mats.data(), mats.size() * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const double *d_w = e->d_mats, *d_Pm = e->d_mats + Q * Q, *d_cab = e->d_mats + 2 * Q * Q;
+    bool exact = (e->nonedge_mode == 1) || (e->nonedge_mode == 0 && N <= 32768);
+    double adj[2] = {0.0, 0.0}, all[2] = {0.0, 0.0};
+    if (exact) {
+        const uint32_t g = (N + BLOCK - 1) / BLOCK;
+        CHK(ensure_partials(e, size_t(g) * g * (NE_NP + 1)));
+        DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_exact<QQ>), dim3(g, g), dim3(BLOCK), 0, e->stream, e->d_psi, N, d_Pm,
+                                         d_cab, invN, int(want_entropy), e->d_partials));
+        HIPCHK(hipGetLastError());
+        CHK(fold_to_host(e, g * g, NE_NP, NE_NP + 1, all));
+        CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (NE_NP + 1)));
+        DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_exact_adj<QQ>), dim3(e->n_blk), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
+                                         e->d_nbr, e->d_psi, d_Pm, d_cab, e->d_blk_row, invN, int(want_entropy),
+                                         e->d_partials));
+        HIPCHK(hipGetLastError());
+        CHK(fold_to_host(e, e->n_blk, NE_NP, NE_NP + 1, adj));
+    } else {
+        const int K = choose_series_order(e, wmax);
+        const int Kent = want_entropy ? K : 0;  // entropy term k uses M_{k+1}: orders 1..K as well
+        (void)Kent;
+        int T = 0, sz = 1;
+        for (int k = 1; k <= K; ++k) { sz *= int(Q); T += sz; }
+        const uint32_t rows_per_blk = 8192;
+        const uint32_t nb = std::max<uint32_t>(1, (N + rows_per_blk - 1) / rows_per_blk);
+        CHK(ensure_partials(e, size_t(nb) * T));
+        CHK(ensure_small(e, size_t(T)));
+        hipLaunchKernelGGL(k_moments, dim3(nb), dim3(BLOCK), 0, e->stream, e->d_psi, N, int(Q), K, rows_per_blk, T, e->d_partials);
+        hipLaunchKernelGGL(k_fold_columns, dim3((T + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_partials, nb,
+                           uint32_t(T), e->d_small);
+        HIPCHK(hipGetLastError());
+        std::vector<double> Mk(T);
+        HIPCHK(hipMemcpyAsync(Mk.data(), e->d_small, size_t(T) * 8, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        std::vector<double> vmat(Q * Q);
+        for (uint32_t a = 0; a < Q * Q; ++a) vmat[a] = cabm[a] * std::log(cabm[a]);
+        double Nk = 1.0;
+        size_t off = 0, tsz = 1;
+        for (int k = 1; k <= K; ++k) {
+            tsz *= Q;
+            Nk *= double(N);
+            std::vector<const double *> ms(k, wmat);
+            all[0] -= contract(Mk.data() + off, Q, unsigned(k), ms) / (double(k) * Nk);
+            if (want_entropy) {  // term (k-1): (u/N)(y/N)^(k-1) -> <M_k, (v x cab^(k-1)) M_k> / N^k
+                std::vector<const double *> me(k, cabm);
+                me[0] = vmat.data();
+                all[1] += contract(Mk.data() + off, Q, unsigned(k), me) / Nk;
+            }
+            off += tsz;
+        }
+        CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (NE_NP + 1)));
+        DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_adj<QQ>), dim3(e->n_blk), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
+                                         e->d_nbr, e->d_psi, d_w, d_cab, e->d_blk_row, invN, int(want_entropy), e->d_partials));
+        HIPCHK(hipGetLastError());
+        CHK(fold_to_host(e, e->n_blk, NE_NP, NE_NP + 1, adj));
+    }
+    out[0] = (all[0] - adj[0]) / (2.0 * N);
+    out[1] = (all[1] - adj[1]) / (2.0 * N);
+    return SBMBP_OK;
+}
+
+int row_sums(sbmbp_engine *e, std::vector<double> &out /* 2Q + Q*Q */) {
+    const uint32_t Q = e->Q;
+    const uint32_t T = 2 * Q + Q * Q;
+    const uint32_t rows_per_blk = 8192;
+    const uint32_t nb = std::max<uint32_t>(1, (e->N + rows_per_blk - 1) / rows_per_blk);
+    CHK(ensure_partials(e, size_t(nb) * T));
+    CHK(ensure_small(e, T));
+    DISPATCH_Q(Q, hipLaunchKernelGGL((k_row_sums<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_psi,
+                                     e->d_true, e->N, rows_per_blk, e->d_partials));
+    hipLaunchKernelGGL(k_fold_columns, dim3((T + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_partials, nb, T, e->d_small);
+    HIPCHK(hipGetLastError());
+    out.resize(T);
+    HIPCHK(hipMemcpyAsync(out.data(), e->d_small, size_t(T) * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SBMBP_OK;
+}
+
+int em_expect(sbmbp_engine *e, double *na_e, double *nna_e, double *cab_e) {
+    if (!e->have_params || !e->have_state) { set_error("engine has no parameters or no state"); return SBMBP_ERR_STATE; }
+    const uint32_t Q = e->Q;
+    std::vector<double> rs;
+    CHK(row_sums(e, rs));
+    const double *na = rs.data(), *nna = rs.data() + Q;
+    const uint32_t T = Q * (Q + 1) / 2;
+    const uint32_t nb = uint32_t(std::min<uint64_t>(2048, std::max<uint64_t>(1, (e->E2 + BLOCK - 1) / BLOCK)));
+    CHK(ensure_partials(e, size_t(nb) * (T + 1)));
+    // k_em_edges reads cab/invN from the parameter block, which is in sync with the host mirror here:
+    // sbmbp_set_params uploads, and inside learning the preceding converge uploaded.
+    const double *M = e->d_M[e->cur];
+    if (e->dc == 2) {
+        DISPATCH_Q(Q, hipLaunchKernelGGL((k_em_edges<QQ, true>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_rev,
+                                         e->d_nbr, e->d_src, M, uint32_t(e->E2), e->d_P, e->d_partials));
+    } else {
+        DISPATCH_Q(Q, hipLaunchKernelGGL((k_em_edges<QQ, false>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_rev,
+                                         e->d_nbr, e->d_src, M, uint32_t(e->E2), e->d_P, e->d_partials));
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<double> tri(T);
+    CHK(fold_to_host(e, nb, T, T + 1, tri.data()));
+    std::vector<double> ce(Q * Q, 0.0);
+    uint32_t t = 0;
+    for (uint32_t q1 = 0; q1 < Q; ++q1)
+        for (uint32_t q2 = q1; q2 < Q; ++q2, ++t) { ce[q1 * Q + q2] = tri[t]; ce[q2 * Q + q1] = tri[t]; }
+    // rescaling of belief_propagation.cpp:967-988
+    const double EPS = 1.0e-50;
+    const double *nn = (e->dc == 0) ? na : nna;
+    for (uint32_t q1 = 0; q1 < Q; ++q1)
+        for (uint32_t q2 = q1; q2 < Q; ++q2)
+            if (na[q1] > EPS && na[q2] > EPS) {
+                if (q1 != q2) {
+                    ce[q1 * Q + q2] *= double(e->N) / (nn[q1] * nn[q2]);
+                    ce[q2 * Q + q1] = ce[q1 * Q + q2];
+                } else {
+                    ce[q1 * Q + q2] *= 2. * double(e->N) / (nn[q1] * nn[q2]);
+                }
+            }
+    if (na_e) std::copy(na, na + Q, na_e);
+    if (nna_e) std::copy(nna, nna + Q, nna_e);
+    if (cab_e) std::copy(ce.begin(), ce.end(), cab_e);
+    return SBMBP_OK;
+}
+
+int free_energy_impl(sbmbp_engine *e, double *f, double *parts) {
+    if (!e->field_fresh) CHK(refresh_field(e));
+    double se[4], ne[2];
+    CHK(site_edge_terms(e, false, se));
+    CHK(nonedge_terms(e, false, ne));
+    const double N = double(e->N);
+    double f_site = se[0] / N, f_edge = se[1] / (2.0 * N);
+    if (e->dc == 1) { f_site += e->sum_log_didl / N; f_edge += e->sum_log_didl / (2.0 * N); }  // SURVEY A.3 dc-1 note
+    const double f_non = ne[0];
+    if (parts) { parts[0] = f_site; parts[1] = f_edge; parts[2] = f_non; }
+    if (f) *f = -f_site + f_edge + f_non;
+    return SBMBP_OK;
+}
+
+int entropy_impl(sbmbp_engine *e, double *ent, double *parts) {
+    if (e->dc != 0) {  // the reference evaluates 0/0 in e_site for deg_corr_flag != 0 (bp.cpp:550-556)
+        const double nan = std::numeric_limits<double>::quiet_NaN();
+        if (parts) { parts[0] = nan; parts[1] = nan; parts[2] = 0.0; }
+        if (ent) *ent = nan;
+        return SBMBP_OK;
+    }
+    if (!e->field_fresh) CHK(refresh_field(e));
+    double se[4], ne[2];
+    CHK(site_edge_terms(e, true, se));
+    CHK(nonedge_terms(e, true, ne));
+    const double N = double(e->N);
+    const double e_site = se[2] / N, e_edge = se[3] / (2.0 * N), e_non = ne[1];
+    if (parts) { parts[0] = e_site; parts[1] = e_edge; parts[2] = e_non; }
+    if (ent) *ent = -e_site + e_edge - e_non;
+    return SBMBP_OK;
+}
+
+int overlap_impl(sbmbp_engine *e, double *ov, double *Cout) {
+    if (!e->have_state) { set_error("engine has no state"); return SBMBP_ERR_STATE; }
+    const uint32_t Q = e->Q;
+    std::vector<double> rs;
+    CHK(row_sums(e, rs));
+    const double *C = rs.data() + 2 * Q;
+    if (Cout) std::copy(C, C + Q * Q, Cout);
+    if (ov) {
+        std::vector<uint32_t> perm(Q);
+        std::iota(perm.begin(), perm.end(), 0u);
+        double best = -1.0;
+        do {  // compute_overlap (bp.cpp:775-811): all Q! permutations for Q <= 8
+            double s = 0.0;
+            for (uint32_t a = 0; a < Q; ++a) s += C[a * Q + perm[a]];
+            s /= double(e->N);
+            if (s > best) best = s;
+        } while (std::next_permutation(perm.begin(), perm.end()));
+        *ov = best;
+    }
+    return SBMBP_OK;
+}
+
+void apply_params_host(sbmbp_engine *e, const double *cab, const uint32_t *na, double beta) {
+    const uint32_t Q = e->Q;
+    e->cab.assign(cab, cab + Q * Q);
+    e->na.assign(na, na + Q);
+    e->eta.resize(Q);
+    for (uint32_t q = 0; q < Q; ++q) e->eta[q] = 1.0 * e->na[q] / e->N;  // bp.cpp:307
+    e->beta = beta;
+    e->have_params = true;
+    e->field_fresh = false;
+}
+
+}  // namespace
+
+// =============================================== C ABI ==========================================
+extern "C" {
+
+const char *sbmbp_strerror(int code) {
+    switch (code) {
+        case SBMBP_OK: return "ok";
+        case SBMBP_ERR_ARG: return "invalid argument";
+        case SBMBP_ERR_HIP: return "HIP runtime error";
+        case SBMBP_ERR_NODEVICE: return "no usable GPU (this engine has no CPU fallback)";
+        case SBMBP_ERR_STATE: return "call order violated";
+        case SBMBP_ERR_IO: return "I/O error";
+        case SBMBP_ERR_UNSUPPORTED: return "unsupported configuration";
+        case SBMBP_ERR_NOMEM: return "out of device memory";
+        default: return "unknown error";
+    }
+}
+const char *sbmbp_last_error(void) { return get_error().c_str(); }
+const char *sbmbp_version(void) { return "sbmbp-hip 0.1 (gfx950)"; }
+
+int sbmbp_graph_load_edgelist(sbmbp_graph_t **out, const char *path, uint32_t n_vertices) {
+    if (!out || !path) return SBMBP_ERR_ARG;
+    std::vector<uint32_t> pairs;
+    CHK(read_edgelist(path, pairs));
+    auto *g = new sbmbp_graph();
+    int r = graph_from_pairs(*g, pairs.data(), pairs.size() / 2, n_vertices);
+    if (r != SBMBP_OK) { delete g; return r; }
+    *out = g;
+    return SBMBP_OK;
+}
+int sbmbp_graph_from_edges(sbmbp_graph_t **out, const uint32_t *pairs, uint64_t n_pairs, uint32_t n_vertices) {
+    if (!out || (!pairs && n_pairs)) return SBMBP_ERR_ARG;
+    auto *g = new sbmbp_graph();
+    int r = graph_from_pairs(*g, pairs, n_pairs, n_vertices);
+    if (r != SBMBP_OK) { delete g; return r; }
+    *out = g;
+    return SBMBP_OK;
+}
+int sbmbp_graph_from_csr(sbmbp_graph_t **out, uint32_t n, uint64_t e2, const uint64_t *row_ptr, const uint32_t *nbr,
+                         const uint32_t *rev) {
+    if (!out) return SBMBP_ERR_ARG;
+    auto *g = new sbmbp_graph();
+    int r = graph_from_csr(*g, n, e2, row_ptr, nbr, rev);
+    if (r != SBMBP_OK) { delete g; return r; }
+    *out = g;
+    return SBMBP_OK;
+}
+uint32_t sbmbp_graph_num_vertices(const sbmbp_graph_t *g) { return g ? g->n : 0; }
+uint64_t sbmbp_graph_num_directed_edges(const sbmbp_graph_t *g) { return g ? g->e2() : 0; }
+uint32_t sbmbp_graph_max_degree(const sbmbp_graph_t *g) { return g ? g->max_degree : 0; }
+int sbmbp_graph_copy_csr(const sbmbp_graph_t *g, uint64_t *row_ptr, uint32_t *nbr, uint32_t *rev) {
+    if (!g) return SBMBP_ERR_ARG;
+    if (row_ptr) std::copy(g->row_ptr.begin(), g->row_ptr.end(), row_ptr);
+    if (nbr) std::copy(g->nbr.begin(), g->nbr.end(), nbr);
+    if (rev) std::copy(g->rev.begin(), g->rev.end(), rev);
+    return SBMBP_OK;
+}
+void sbmbp_graph_destroy(sbmbp_graph_t *g) { delete g; }
+
+int sbmbp_param_from_epsilon_c(uint32_t N, uint32_t Q, double epsilon, double c, double *cab, uint32_t *na) {
+    if (!cab || !na || Q < 1) return SBMBP_ERR_ARG;
+    param_from_epsilon_c(N, Q, epsilon, c, cab, na);
+    return SBMBP_OK;
+}
+int sbmbp_param_from_direct(uint32_t N, uint32_t Q, const double *pa, const double *cab_upper, double *cab, uint32_t *na) {
+    if (!cab || !na || !pa || !cab_upper || Q < 1) return SBMBP_ERR_ARG;
+    param_from_direct(N, Q, pa, cab_upper, cab, na);
+    return SBMBP_OK;
+}
+
+int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint32_t dc, int device) {
+    if (!out || !g) return SBMBP_ERR_ARG;
+    if (Q < 2 || Q > SBMBP_MAX_Q) { set_error("Q must be in [2, 8]"); return SBMBP_ERR_UNSUPPORTED; }
+    if (dc > 2) { set_error("deg_corr_flag must be 0, 1 or 2"); return SBMBP_ERR_ARG; }
+    if (g->n == 0) { set_error("empty graph"); return SBMBP_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device visible; the engine has no CPU fallback");
+        return SBMBP_ERR_NODEVICE;
+    }
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    auto *e = new sbmbp_engine();
+    HIPCHK(hipGetDevice(&e->device));
+    e->N = g->n;
+    e->Q = Q;
+    e->dc = dc;
+    e->E2 = g->e2();
+    HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->own_stream = true;
+
+    // work decomposition: greedy segments of <= CAP edges and <= RCAP rows; a row above CAP is a hub segment
+    const uint32_t cap = uint32_t(frame_cap(Q)), rcap = uint32_t(frame_rcap(Q));
+    std::vector<uint32_t> blk_row, hub_row, hub_blk;
+    blk_row.push_back(0);
+    uint32_t rows = 0, edges = 0;
+    for (uint32_t i = 0; i < g->n; ++i) {
+        const uint32_t d = g->deg(i);
+        if (d > cap) {
+            if (rows) { blk_row.push_back(i); rows = 0; edges = 0; }
+            hub_row.push_back(i);
+            hub_blk.push_back(uint32_t(blk_row.size() - 1));
+            blk_row.push_back(i + 1);
+            continue;
+        }
+        if (rows + 1 > rcap || edges + d > cap) { blk_row.push_back(i); rows = 0; edges = 0; }
+        rows++;
+        edges += d;
+    }
+    if (blk_row.back() != g->n) blk_row.push_back(g->n);
+    e->n_blk = uint32_t(blk_row.size() - 1);
+    e->n_hub = uint32_t(hub_row.size());
+
+    std::vector<uint32_t> rp32(size_t(g->n) + 1);
+    for (size_t i = 0; i <= g->n; ++i) rp32[i] = uint32_t(g->row_ptr[i]);
+    e->h_row_ptr = rp32;
+    int r;
+#define TRY(x) if ((r = (x)) != SBMBP_OK) { sbmbp_destroy(e); return r; }
+#define TRYHIP(x) do { hipError_t _h = (x); if (_h != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(_h)); sbmbp_destroy(e); return SBMBP_ERR_HIP; } } while (0)
+    TRY(dev_alloc(e, &e->d_row_ptr, rp32.size()));
+    TRY(dev_alloc(e, &e->d_rev, e->E2));
+    TRY(dev_alloc(e, &e->d_nbr, e->E2));
+    TRY(dev_alloc(e, &e->d_blk_row, blk_row.size()));
+    TRY(dev_alloc(e, &e->d_hub_row, hub_row.size()));
+    TRY(dev_alloc(e, &e->d_hub_blk, hub_blk.size()));
+    TRY(dev_alloc(e, &e->d_true, e->N));
+    TRY(dev_alloc(e, &e->d_clamp, e->N));
+    TRY(dev_alloc(e, &e->d_M[0], e->E2 * Q));
+    TRY(dev_alloc(e, &e->d_M[1], e->E2 * Q));
+    TRY(dev_alloc(e, &e->d_psi, size_t(e->N) * Q));
+    TRY(dev_alloc(e, &e->d_P, 1));
+    TRY(dev_alloc(e, &e->d_mats, 3 * Q * Q));
+    e->hist_cap = 4096;
+    TRY(dev_alloc(e, &e->d_hist, e->hist_cap));
+    TRY(ensure_partials(e, size_t(e->n_blk) * (QMAX + 1)));
+    TRY(ensure_small(e, 8192));
+    TRYHIP(hipMemcpyAsync(e->d_row_ptr, rp32.data(), rp32.size() * 4, hipMemcpyHostToDevice, e->stream));
+    if (e->E2) {
+        TRYHIP(hipMemcpyAsync(e->d_rev, g->rev.data(), e->E2 * 4, hipMemcpyHostToDevice, e->stream));
+        TRYHIP(hipMemcpyAsync(e->d_nbr, g->nbr.data(), e->E2 * 4, hipMemcpyHostToDevice, e->stream));
+    }
+    TRYHIP(hipMemcpyAsync(e->d_blk_row, blk_row.data(), blk_row.size() * 4, hipMemcpyHostToDevice, e->stream));
+    if (e->n_hub) {
+        TRYHIP(hipMemcpyAsync(e->d_hub_row, hub_row.data(), hub_row.size() * 4, hipMemcpyHostToDevice, e->stream));
+        TRYHIP(hipMemcpyAsync(e->d_hub_blk, hub_blk.data(), hub_blk.size() * 4, hipMemcpyHostToDevice, e->stream));
+    }
+    TRYHIP(hipMemsetAsync(e->d_true, 0, size_t(e->N) * 4, e->stream));
+    TRYHIP(hipMemsetAsync(e->d_clamp, 0xff, size_t(e->N) * 4, e->stream));
+    TRYHIP(hipMemsetAsync(e->d_partials, 0, e->partials_cap * 8, e->stream));
+    if (dc == 2) {
+        TRY(dev_alloc(e, &e->d_src, e->E2));
+        hipLaunchKernelGGL(k_fill_src, dim3((e->N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->N, e->d_src);
+    }
+    if (dc == 1) {  // sum over directed edges of log(d_i d_l) = 2 sum_i d_i log d_i
+        double s = 0.0;
+        for (uint32_t i = 0; i < g->n; ++i) { const double d = double(g->deg(i)); if (d > 0) s += 2.0 * d * std::log(d); }
+        e->sum_log_didl = s;
+    }
+    TRYHIP(hipStreamSynchronize(e->stream));
+#undef TRY
+#undef TRYHIP
+    *out = e;
+    return SBMBP_OK;
+}
+
+void sbmbp_destroy(sbmbp_engine_t *e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    void *ptrs[] = {e->d_row_ptr, e->d_rev, e->d_nbr, e->d_src, e->d_blk_row, e->d_hub_row, e->d_hub_blk, e->d_true,
+                    e->d_clamp, e->d_M[0], e->d_M[1], e->d_psi, e->d_P, e->d_partials, e->d_small, e->d_hist, e->d_mats};
+    for (void *p : ptrs) if (p) hipFree(p);
+    for (auto ev : e->ev) hipEventDestroy(ev);
+    if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int sbmbp_set_stream(sbmbp_engine_t *e, void *hip_stream) {
+    if (!e) return SBMBP_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->own_stream && e->stream) HIPCHK(hipStreamDestroy(e->stream));
+    if (hip_stream) { e->stream = static_cast<hipStream_t>(hip_stream); e->own_stream = false; }
+    else { HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)); e->own_stream = true; }
+    return SBMBP_OK;
+}
+
+static int upload_labels(sbmbp_engine_t *e, const int32_t *conf, const uint32_t *true_conf, uint32_t flag, int conditional) {
+    if (true_conf) {
+        for (uint32_t i = 0; i < e->N; ++i)
+            if (true_conf[i] >= e->Q) { set_error("true_conf entry out of range"); return SBMBP_ERR_ARG; }
+        e->true_conf.assign(true_conf, true_conf + e->N);
+        HIPCHK(hipMemcpyAsync(e->d_true, true_conf, size_t(e->N) * 4, hipMemcpyHostToDevice, e->stream));
+    }
+    // bp_conditional skips rows with conf_planted_ != -1 (bp.cpp:1104); with -i 0 the planted vector
+    // is never stored, so nothing is clamped.
+    e->has_clamp = false;
+    if (conditional && flag != 0 && conf) {
+        for (uint32_t i = 0; i < e->N; ++i) {
+            if (conf[i] < -1 || conf[i] >= int32_t(e->Q)) { set_error("conf entry out of range"); return SBMBP_ERR_ARG; }
+            if (conf[i] != -1) e->has_clamp = true;
+        }
+        HIPCHK(hipMemcpyAsync(e->d_clamp, conf, size_t(e->N) * 4, hipMemcpyHostToDevice, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SBMBP_OK;
+}
+
+int sbmbp_init_messages(sbmbp_engine_t *e, uint32_t flag, const int32_t *conf, const uint32_t *true_conf, uint32_t seed,
+                        int conditional) {
+    if (!e) return SBMBP_ERR_ARG;
+    if (flag >= 4) { set_error("bp_messages_init_flag must be < 4"); return SBMBP_ERR_ARG; }  // assert at bp.cpp:106
+    if (flag != 0 && !conf) { set_error("init flag != 0 needs a conf vector"); return SBMBP_ERR_ARG; }
+    std::vector<double> psi, msg;
+    init_state_host(e->N, e->h_row_ptr.data(), e->E2, e->Q, flag, conf, seed, psi, msg);
+    CHK(upload_labels(e, conf, true_conf, flag, conditional));
+    return sbmbp_set_state(e, psi.data(), msg.data());
+}
+
+int sbmbp_init_messages_device(sbmbp_engine_t *e, uint64_t seed, const uint32_t *true_conf) {
+    if (!e) return SBMBP_ERR_ARG;
+    CHK(upload_labels(e, nullptr, true_conf, 0, 0));
+    hipLaunchKernelGGL(k_init_random, dim3((e->N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_psi, uint64_t(e->N),
+                       int(e->Q), seed, 0x1234567ull);
+    if (e->E2)
+        hipLaunchKernelGGL(k_init_random, dim3(uint32_t((e->E2 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, e->stream,
+                           e->d_M[e->cur], e->E2, int(e->Q), seed, 0xabcdef01ull);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->have_state = true;
+    e->field_fresh = false;
+    return SBMBP_OK;
+}
+
+int sbmbp_set_params(sbmbp_engine_t *e, const double *cab, const uint32_t *na, double beta) {
+    if (!e || !cab || !na) return SBMBP_ERR_ARG;
+    apply_params_host(e, cab, na, beta);
+    return upload_params(e, 0.0);
+}
+int sbmbp_get_params(sbmbp_engine_t *e, double *cab, uint32_t *na) {
+    if (!e || !e->have_params) return SBMBP_ERR_STATE;
+    if (cab) std::copy(e->cab.begin(), e->cab.end(), cab);
+    if (na) std::copy(e->na.begin(), e->na.end(), na);
+    return SBMBP_OK;
+}
+
+int sbmbp_set_state(sbmbp_engine_t *e, const double *psi, const double *msg_out) {
+    if (!e) return SBMBP_ERR_ARG;
+    if (psi) HIPCHK(hipMemcpyAsync(e->d_psi, psi, size_t(e->N) * e->Q * 8, hipMemcpyHostToDevice, e->stream));
+    if (msg_out && e->E2) HIPCHK(hipMemcpyAsync(e->d_M[e->cur], msg_out, e->E2 * e->Q * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (psi && msg_out) e->have_state = true;
+    e->field_fresh = false;
+    return SBMBP_OK;
+}
+int sbmbp_get_state(sbmbp_engine_t *e, double *psi, double *msg_out) {
+    if (!e) return SBMBP_ERR_ARG;
+    if (psi) HIPCHK(hipMemcpyAsync(psi, e->d_psi, size_t(e->N) * e->Q * 8, hipMemcpyDeviceToHost, e->stream));
+    if (msg_out && e->E2) HIPCHK(hipMemcpyAsync(msg_out, e->d_M[e->cur], e->E2 * e->Q * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SBMBP_OK;
+}
+int sbmbp_get_field(sbmbp_engine_t *e, double *h) {
+    if (!e || !h) return SBMBP_ERR_ARG;
+    CHK(refresh_field(e));
+    dev_params P;
+    HIPCHK(hipMemcpyAsync(&P, e->d_P, sizeof P, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (uint32_t q = 0; q < e->Q; ++q) h[q] = P.hN[q] * double(e->N);
+    return SBMBP_OK;
+}
+
+int sbmbp_set_schedule(sbmbp_engine_t *e, double field_mix, uint32_t check_every) {
+    if (!e || !(field_mix > 0.0) || field_mix > 1.0 || check_every < 1) return SBMBP_ERR_ARG;
+    e->field_mix = field_mix;
+    e->check_every = check_every;
+    return SBMBP_OK;
+}
+
+int sbmbp_converge(sbmbp_engine_t *e, double crit, uint32_t max_sweeps, double damping, int *niter, double *last) {
+    if (!e) return SBMBP_ERR_ARG;
+    return run_sweeps(e, crit, max_sweeps, damping, niter, last);
+}
+int sbmbp_sweep(sbmbp_engine_t *e, double damping, uint32_t n_sweeps, double *last) {
+    if (!e) return SBMBP_ERR_ARG;
+    const uint32_t keep = e->check_every;
+    e->check_every = std::max<uint32_t>(keep, 64);  // no convergence test: sync rarely
+    int r = run_sweeps(e, -1.0, n_sweeps, damping, nullptr, last);
+    e->check_every = keep;
+    return r;
+}
+
+int sbmbp_free_energy(sbmbp_engine_t *e, double *f, double *parts) {
+    if (!e) return SBMBP_ERR_ARG;
+    return free_energy_impl(e, f, parts);
+}
+int sbmbp_entropy(sbmbp_engine_t *e, double *ent, double *parts) {
+    if (!e) return SBMBP_ERR_ARG;
+    return entropy_impl(e, ent, parts);
+}
+int sbmbp_set_nonedge_mode(sbmbp_engine_t *e, int mode, int order) {
+    if (!e || mode < 0 || mode > 2 || order < 0 || order > 4) return SBMBP_ERR_ARG;
+    e->nonedge_mode = mode;
+    e->series_order = order;
+    return SBMBP_OK;
+}
+int sbmbp_em_expectations(sbmbp_engine_t *e, double *na_e, double *nna_e, double *cab_e) {
+    if (!e) return SBMBP_ERR_ARG;
+    return em_expect(e, na_e, nna_e, cab_e);
+}
+int sbmbp_confusion(sbmbp_engine_t *e, double *C) {
+    if (!e || !C) return SBMBP_ERR_ARG;
+    return overlap_impl(e, nullptr, C);
+}
+int sbmbp_overlap(sbmbp_engine_t *e, double *ov) {
+    if (!e || !ov) return SBMBP_ERR_ARG;
+    return overlap_impl(e, ov, nullptr);
+}
+
+int sbmbp_inference(sbmbp_engine_t *e, float conv_crit, uint32_t time_conv, float dumping_rate, sbmbp_infer_result *out) {
+    if (!e || !out) return SBMBP_ERR_ARG;
+    // belief_propagation::inference (bp.cpp:77-99); crit and damping arrive as float, compared as double (:406)
+    CHK(run_sweeps(e, double(conv_crit), time_conv, double(dumping_rate), &out->niter, &out->last_maxdiff));
+    CHK(free_energy_impl(e, &out->free_energy, nullptr));
+    CHK(entropy_impl(e, &out->entropy, nullptr));
+    CHK(overlap_impl(e, &out->overlap, nullptr));
+    return SBMBP_OK;
+}
+
+int sbmbp_learning(sbmbp_engine_t *e, float learning_conv_crit, uint32_t learning_max_time, float learning_rate,
+                   float dumping_rate, sbmbp_learn_result *out) {
+    if (!e || !out) return SBMBP_ERR_ARG;
+    if (!e->have_params || !e->have_state) { set_error("set_params and init_messages must precede learning"); return SBMBP_ERR_STATE; }
+    const uint32_t Q = e->Q;
+    std::vector<double> na_e(Q), nna_e(Q), cab_e(Q * Q);
+    double fold = 0.0, fdiff = 1.0;
+    out->em_steps = 0;
+    out->status = 0;
+    out->total_sweeps = 0;
+    const uint64_t sweeps0 = e->sweeps;
+    for (uint32_t t = 0; t < learning_max_time; ++t) {  // belief_propagation::learning (bp.cpp:27-47)
+        if (fdiff < learning_conv_crit) learning_conv_crit = float(double(learning_conv_crit) * 0.1);
+        int niter;
+        double last;
+        CHK(run_sweeps(e, double(learning_conv_crit), learning_max_time, double(dumping_rate), &niter, &last));
+        CHK(em_expect(e, na_e.data(), nna_e.data(), cab_e.data()));
+        double fnew;
+        CHK(free_energy_impl(e, &fnew, nullptr));
+        fdiff = std::fabs(fnew - fold);
+        fold = fnew;
+        if (std::isnan(fold) || std::isinf(fold)) { out->status = 2; break; }
+        if (fdiff < learning_conv_crit) { out->status = 1; break; }
+        // learning_step (bp.cpp:53-75)
+        std::vector<uint32_t> na(e->na);
+        uint32_t rest = e->N;
+        for (uint32_t i = 0; i + 1 < Q; ++i) {
+            na[i] = unsigned(int(learning_rate * na_e[i] + (1.0 - learning_rate) * na[i]));
+            rest -= na[i];
+        }
+        na[Q - 1] = rest;
+        std::vector<double> cab(e->cab);
+        for (uint32_t a = 0; a < Q * Q; ++a) cab[a] = learning_rate * cab_e[a] + (1.0 - learning_rate) * cab[a];
+        apply_params_host(e, cab.data(), na.data(), e->beta);
+        out->em_steps++;
+    }
+    out->free_energy = fold;
+    out->total_sweeps = e->sweeps - sweeps0;
+    CHK(upload_params(e, 0.0));
+    CHK(overlap_impl(e, &out->overlap, nullptr));
+    return SBMBP_OK;
+}
+
+int sbmbp_get_stats(sbmbp_engine_t *e, sbmbp_stats *out) {
+    if (!e || !out) return SBMBP_ERR_ARG;
+    out->sweeps = e->sweeps;
+    out->edge_msg_updates = e->sweeps * e->E2;
+    out->sweep_kernel_ms = e->sweep_ms;
+    out->sweep_launches = e->sweep_launches;
+    // B_sweep = E2 (3*8Q + 4) + N (8Q + 8): SURVEY 8(d); dc 2 adds the neighbour index (4 B/edge)
+    out->bytes_per_sweep = double(e->E2) * (24.0 * e->Q + 4.0 + (e->dc == 2 ? 4.0 : 0.0)) + double(e->N) * (8.0 * e->Q + 8.0);
+    out->device_bytes = e->device_bytes;
+    out->n_blocks = e->n_blk;
+    out->n_hub_rows = e->n_hub;
+    return SBMBP_OK;
+}
+int sbmbp_reset_stats(sbmbp_engine_t *e) {
+    if (!e) return SBMBP_ERR_ARG;
+    e->sweeps = 0;
+    e->sweep_ms = 0.0;
+    e->sweep_launches = 0;
+    return SBMBP_OK;
+}
+int sbmbp_set_timing(sbmbp_engine_t *e, int on) {
+    if (!e) return SBMBP_ERR_ARG;
+    e->timing = on != 0;
+    return SBMBP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1012 @@
+// HIP kernels of the BP engine, written for gfx950 (CDNA4: wave64, 256 CUs, 160 KiB LDS/CU).
+//
+// Work decomposition of every edge-parallel kernel ("frame"): the host cuts the CSR row sequence
+// into workgroup segments [blk_row[b], blk_row[b+1]) holding at most CAP directed edges and RCAP
+// rows. Inside a workgroup, phases alternate between one lane per directed edge (coalesced
+// streams of rev/own messages, random gather of the incoming message, Q*Q FMAs) and one lane
+// per row (product over the row's edges out of LDS). Rows with more than CAP edges ("hubs") are
+// handled by a workgroup-per-row kernel. All reductions are fixed-order (block partials + one
+// finalize workgroup): results are bitwise reproducible run to run.
+//
+// Equations: SURVEY.md Appendix A (restating belief_propagation.cpp:991-1071 for the update,
+// :442-504/:562-612/:675-709 for the free energy, :892-989 for the EM expectations).
+#ifndef SBMBP_KERNELS_H
+#define SBMBP_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sbmbp {
+
+constexpr int BLOCK = 256;
+constexpr int QMAX = 8;
+
+// Parameter/state block in HBM, read through scalar loads by every workgroup and rewritten by
+// k_finalize after each sweep (arrays packed with stride Q).
+struct dev_params {
+    double W[QMAX * QMAX];     // sweep weights: cab^beta (dc 0), cab (dc 1), pab = cab/N (dc 2)
+    double cab[QMAX * QMAX];
+    double eta[QMAX];
+    double logeta[QMAX];
+    double hN[QMAX];           // h[q] / N
+    double etaF[QMAX];         // eta[q] * exp(-beta h[q]/N)   (dc 0 field factor)
+    double S[QMAX];            // sum_i g_i psi_i[q] after relaxation (h = cab^T S)
+    double beta, invN, field_mix, crit;
+    double maxdiff;            // of the last executed sweep
+    int conv_iter;             // -1 until the first sweep with maxdiff < crit
+    int sweep_idx;             // sweeps executed in the current converge call
+    int stop;                  // 1: queued sweeps that follow are no-ops
+    int have_prev;             // S holds a previous value (field relaxation)
+};
+
+template <int Q> struct frame_cfg {
+    static constexpr int EPT = (Q <= 2) ? 4 : 2;          // directed edges per lane
+    static constexpr int CAP = BLOCK * EPT;                // edges per workgroup
+    static constexpr int RCAP = (Q <= 4) ? 2 * BLOCK : BLOCK;  // rows per workgroup
+};
+
+template <int Q> __device__ __forceinline__ void load_vec(const double *__restrict__ p, double (&v)[Q]) {
+    if (Q % 2 == 0) {
+        const double2 *p2 = reinterpret_cast<const double2 *>(p);
+#pragma unroll
+        for (int j = 0; j < Q / 2; ++j) { double2 t = p2[j]; v[2 * j] = t.x; v[2 * j + 1] = t.y; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) v[q] = p[q];
+    }
+}
+template <int Q> __device__ __forceinline__ void store_vec(double *__restrict__ p, const double (&v)[Q]) {
+    if (Q % 2 == 0) {
+        double2 *p2 = reinterpret_cast<double2 *>(p);
+#pragma unroll
+        for (int j = 0; j < Q / 2; ++j) p2[j] = make_double2(v[2 * j], v[2 * j + 1]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) p[q] = v[q];
+    }
+}
+
+// sticky-NaN maximum: a NaN difference must never look like convergence
+__device__ __forceinline__ double nanmax(double a, double b) { return (b > a || b != b) ? b : a; }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_nanmax(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = nanmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+// Block reduction of NS sums followed by one sticky-NaN max; thread 0 stores them to out[0..NS].
+// sred: NS+1 doubles per wave (4 waves).
+template <int NS> __device__ __forceinline__ void block_reduce_store(double (&s)[NS], double mx, double *sred, double *out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) s[q] = wave_sum(s[q]);
+    mx = wave_nanmax(mx);
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) sred[wave * (NS + 1) + q] = s[q];
+        sred[wave * (NS + 1) + NS] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+            out[q] = ((sred[q] + sred[(NS + 1) + q]) + sred[2 * (NS + 1) + q]) + sred[3 * (NS + 1) + q];
+        double m = sred[NS];
+        m = nanmax(m, sred[(NS + 1) + NS]);
+        m = nanmax(m, sred[2 * (NS + 1) + NS]);
+        m = nanmax(m, sred[3 * (NS + 1) + NS]);
+        out[NS] = m;
+    }
+}
+
+// exact power-of-two rescale of a Q-vector so that its largest entry has exponent 0; returns the
+// removed exponent (0 when no rescale was needed)
+template <int Q> __device__ __forceinline__ int rescale_pow2(double (&A)[Q]) {
+    double amax = A[0];
+#pragma unroll
+    for (int q = 1; q < Q; ++q) amax = fmax(amax, A[q]);
+    if (amax > 1e-100 && amax < 1e100) return 0;
+    if (!(amax > 0.0) || amax > 1.7e308) return 0;  // zero, NaN or Inf: nothing sensible to do
+    int n = ilogb(amax);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) A[q] = ldexp(A[q], -n);
+    return n;
+}
+
+// b[q] = sum_t W_il[t][q] m[t]   (belief_propagation.cpp:1000-1012)
+template <int Q, bool DC2>
+__device__ __forceinline__ void edge_field(const dev_params *__restrict__ P, const double (&m)[Q], double didl, double (&b)[Q]) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < Q; ++t) {
+            double w = P->W[t * Q + q];
+            if (DC2) { double x = didl * w; w = x / (1.0 + x); }
+            acc += w * m[t];
+        }
+        b[q] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: one synchronous sweep over the rows of this workgroup's segment.
+// partials[b*(Q+1) + q] = sum_rows g_i psi_i[q],  partials[b*(Q+1)+Q] = max |delta message|.
+// ------------------------------------------------------------------------------------------------
+template <int Q, bool DC2>
+__global__ void __launch_bounds__(BLOCK)
+k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr,
+        const double *__restrict__ Mold, double *__restrict__ Mnew, double *__restrict__ psi,
+        const int32_t *__restrict__ clamp, const uint32_t *__restrict__ blk_row,
+        const dev_params *__restrict__ P, int dc, double damp, double *__restrict__ partials) {
+    if (P->stop) return;
+    constexpr int EPT = frame_cfg<Q>::EPT, CAP = frame_cfg<Q>::CAP, RCAP = frame_cfg<Q>::RCAP;
+    __shared__ double sb[CAP * Q];     // b_e[q] of every edge of the segment
+    __shared__ double sA[RCAP * Q];    // unnormalised marginal of every row
+    __shared__ uint32_t srp[RCAP + 1]; // row offsets relative to the segment
+    __shared__ uint16_t srow[CAP];     // row (within segment) of every edge
+    __shared__ uint8_t sfl[RCAP];      // 1 = clamped row
+    __shared__ double sred[4 * (Q + 1)];
+
+    const int tid = threadIdx.x;
+    const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
+    const int nrows = int(r1 - r0);
+    const uint32_t e0 = row_ptr[r0];
+    for (int r = tid; r <= nrows; r += BLOCK) srp[r] = row_ptr[r0 + r] - e0;
+    __syncthreads();
+    const int ne = int(srp[nrows]);
+    if (ne > CAP) return;  // hub row: k_sweep_hub owns this segment (uniform exit, before any other barrier)
+
+    for (int r = tid; r < nrows; r += BLOCK) {
+        const int es = int(srp[r]), ee = int(srp[r + 1]);
+        for (int e = es; e < ee; ++e) srow[e] = uint16_t(r);
+        sfl[r] = (clamp != nullptr && clamp[r0 + r] != -1) ? 1 : 0;
+    }
+    __syncthreads();
+
+    // ---- phase 1: lane per directed edge: gather incoming message, b = W^T m -> LDS
+    double mo[EPT][Q];
+    {
+        uint32_t rk[EPT];
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int le = j * BLOCK + tid;
+            rk[j] = (le < ne) ? rev[e0 + le] : 0u;
+        }
+        double mi[EPT][Q];
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int le = j * BLOCK + tid;
+            if (le < ne) load_vec<Q>(Mold + size_t(rk[j]) * Q, mi[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int le = j * BLOCK + tid;
+            if (le < ne) load_vec<Q>(Mold + size_t(e0 + le) * Q, mo[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int le = j * BLOCK + tid;
+            if (le < ne) {
+                double didl = 0.0;
+                if (DC2) {
+                    const int r = srow[le];
+                    const uint32_t l = nbr[e0 + le];
+                    didl = double(srp[r + 1] - srp[r]) * double(row_ptr[l + 1] - row_ptr[l]);
+                }
+                double b[Q];
+                edge_field<Q, DC2>(P, mi[j], didl, b);
+                store_vec<Q>(&sb[le * Q], b);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: lane per row: A[q] = prod_e b_e[q]; psi_i = normalise(A * eta * F_i)
+    double Sacc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) Sacc[q] = 0.0;
+    for (int r = tid; r < nrows; r += BLOCK) {
+        const int es = int(srp[r]), ee = int(srp[r + 1]);
+        const double di = double(ee - es);
+        const double gi = dc ? di : 1.0;
+        double pv[Q];
+        if (sfl[r]) {  // clamped: marginal and out-messages stay as initialised (bp.cpp:1115-1124)
+            load_vec<Q>(psi + size_t(r0 + r) * Q, pv);
+        } else {
+            double A[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) A[q] = 1.0;
+            for (int e = es; e < ee; ++e) {
+                double b[Q];
+                load_vec<Q>(&sb[e * Q], b);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) A[q] *= b[q];
+                rescale_pow2<Q>(A);
+            }
+            double tot = 0.0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const double fac = dc ? P->eta[q] * exp(-di * P->hN[q]) : P->etaF[q];
+                A[q] *= fac;
+                tot += A[q];
+            }
+            store_vec<Q>(&sA[r * Q], A);
+            const double inv = 1.0 / tot;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) pv[q] = A[q] * inv;
+            store_vec<Q>(psi + size_t(r0 + r) * Q, pv);
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) Sacc[q] += gi * pv[q];
+    }
+    __syncthreads();
+
+    // ---- phase 3: lane per directed edge: cavity, normalise, damp, store
+    double md = 0.0;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int le = j * BLOCK + tid;
+        if (le < ne) {
+            const int r = srow[le];
+            double out[Q];
+            if (sfl[r]) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) out[q] = mo[j][q];
+            } else {
+                double A[Q], b[Q], cav[Q];
+                load_vec<Q>(&sA[r * Q], A);
+                load_vec<Q>(&sb[le * Q], b);
+                bool ok = true;
+                double tot = 0.0;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    cav[q] = A[q] / b[q];
+                    ok = ok && (b[q] > 0.0) && (cav[q] <= 1.7e308);
+                    tot += cav[q];
+                }
+                if (!ok) {  // exact cavity product when a division is unusable (b == 0 or overflow)
+                    const int es = int(srp[r]), ee = int(srp[r + 1]);
+                    const double di = double(ee - es);
+                    tot = 0.0;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) cav[q] = dc ? P->eta[q] * exp(-di * P->hN[q]) : P->etaF[q];
+                    for (int e = es; e < ee; ++e) {
+                        if (e == le) continue;
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) cav[q] *= sb[e * Q + q];
+                        rescale_pow2<Q>(cav);
+                    }
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) tot += cav[q];
+                }
+                const double inv = 1.0 / tot;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const double nv = cav[q] * inv;
+                    md = nanmax(md, fabs(mo[j][q] - nv));
+                    out[q] = damp * nv + (1.0 - damp) * mo[j][q];
+                }
+            }
+            store_vec<Q>(Mnew + size_t(e0 + le) * Q, out);
+        }
+    }
+    block_reduce_store<Q>(Sacc, md, sred, partials + size_t(blockIdx.x) * (Q + 1));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1h: the same update for one hub row per workgroup (degree > CAP): product with a tracked
+// common exponent, two gather passes.
+// ------------------------------------------------------------------------------------------------
+template <int Q, bool DC2>
+__global__ void __launch_bounds__(BLOCK)
+k_sweep_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr,
+            const double *__restrict__ Mold, double *__restrict__ Mnew, double *__restrict__ psi,
+            const int32_t *__restrict__ clamp, const uint32_t *__restrict__ hub_row,
+            const uint32_t *__restrict__ hub_blk, const dev_params *__restrict__ P, int dc, double damp,
+            double *__restrict__ partials) {
+    if (P->stop) return;
+    __shared__ double sAq[BLOCK * Q];
+    __shared__ int sex[BLOCK];
+    __shared__ double sred[4 * (Q + 1)];
+    const int tid = threadIdx.x;
+    const uint32_t i = hub_row[blockIdx.x];
+    const uint32_t e0 = row_ptr[i], d = row_ptr[i + 1] - e0;
+    const double di = double(d);
+    const bool clamped = (clamp != nullptr && clamp[i] != -1);
+    double Sacc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) Sacc[q] = 0.0;
+    double md = 0.0;
+    if (clamped) {
+        for (uint32_t le = tid; le < d; le += BLOCK) {
+            double m[Q];
+            load_vec<Q>(Mold + size_t(e0 + le) * Q, m);
+            store_vec<Q>(Mnew + size_t(e0 + le) * Q, m);
+        }
+        if (tid == 0) {
+            double pv[Q];
+            load_vec<Q>(psi + size_t(i) * Q, pv);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) Sacc[q] = (dc ? di : 1.0) * pv[q];
+        }
+    } else {
+        double A[Q];
+        int ex = 0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) A[q] = 1.0;
+        for (uint32_t le = tid; le < d; le += BLOCK) {
+            double m[Q], b[Q];
+            load_vec<Q>(Mold + size_t(rev[e0 + le]) * Q, m);
+            double didl = 0.0;
+            if (DC2) { const uint32_t l = nbr[e0 + le]; didl = di * double(row_ptr[l + 1] - row_ptr[l]); }
+            edge_field<Q, DC2>(P, m, didl, b);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) A[q] *= b[q];
+            ex += rescale_pow2<Q>(A);
+        }
+        store_vec<Q>(&sAq[tid * Q], A);
+        sex[tid] = ex;
+        __syncthreads();
+        for (int s = BLOCK / 2; s > 0; s >>= 1) {
+            if (tid < s) {
+                double o[Q];
+                load_vec<Q>(&sAq[(tid + s) * Q], o);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) A[q] *= o[q];
+                ex += sex[tid + s];
+                ex += rescale_pow2<Q>(A);
+                store_vec<Q>(&sAq[tid * Q], A);
+                sex[tid] = ex;
+            }
+            __syncthreads();
+        }
+        load_vec<Q>(&sAq[0], A);  // every lane: the row product (common exponent dropped: only ratios matter)
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            A[q] *= dc ? P->eta[q] * exp(-di * P->hN[q]) : P->etaF[q];
+            tot += A[q];
+        }
+        const double inv = 1.0 / tot;
+        if (tid == 0) {
+            double pv[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { pv[q] = A[q] * inv; Sacc[q] = (dc ? di : 1.0) * pv[q]; }
+            store_vec<Q>(psi + size_t(i) * Q, pv);
+        }
+        for (uint32_t le = tid; le < d; le += BLOCK) {
+            double m[Q], b[Q], mo[Q], out[Q];
+            load_vec<Q>(Mold + size_t(rev[e0 + le]) * Q, m);
+            load_vec<Q>(Mold + size_t(e0 + le) * Q, mo);
+            double didl = 0.0;
+            if (DC2) { const uint32_t l = nbr[e0 + le]; didl = di * double(row_ptr[l + 1] - row_ptr[l]); }
+            edge_field<Q, DC2>(P, m, didl, b);
+            double ct = 0.0, cav[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { cav[q] = (b[q] > 0.0) ? A[q] / b[q] : 0.0; ct += cav[q]; }
+            const double ci = 1.0 / ct;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const double nv = cav[q] * ci;
+                md = nanmax(md, fabs(mo[q] - nv));
+                out[q] = damp * nv + (1.0 - damp) * mo[q];
+            }
+            store_vec<Q>(Mnew + size_t(e0 + le) * Q, out);
+        }
+    }
+    block_reduce_store<Q>(Sacc, md, sred, partials + size_t(hub_blk[blockIdx.x]) * (Q + 1));
+}
+
+// ------------------------------------------------------------------------------------------------
+// sum_i g_i psi_i[q] over row chunks (init_h, belief_propagation.cpp:320-332); chunk c covers rows
+// [c*rows_per_blk, ...). Writes partials[c*(Q+1) + q]; slot Q (max) = 0.
+// ------------------------------------------------------------------------------------------------
+template <int Q>
+__global__ void __launch_bounds__(BLOCK)
+k_psi_sum(const uint32_t *__restrict__ row_ptr, const double *__restrict__ psi, uint32_t n_rows, uint32_t rows_per_blk,
+          int dc, double *__restrict__ partials) {
+    __shared__ double sred[4 * (Q + 1)];
+    double S[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) S[q] = 0.0;
+    const uint32_t lo = blockIdx.x * rows_per_blk;
+    const uint32_t hi = min(n_rows, lo + rows_per_blk);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += BLOCK) {
+        double pv[Q];
+        load_vec<Q>(psi + size_t(i) * Q, pv);
+        const double gi = dc ? double(row_ptr[i + 1] - row_ptr[i]) : 1.0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) S[q] += gi * pv[q];
+    }
+    block_reduce_store<Q>(S, 0.0, sred, partials + size_t(blockIdx.x) * (Q + 1));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: fold the workgroup partials in a fixed order, relax the field, refresh h/exph, record the
+// convergence state. mode 0: after a sweep; mode 1: field initialisation (no sweep bookkeeping);
+// mode 2: exact field refresh (no relaxation, no bookkeeping).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK)
+k_finalize(const double *__restrict__ partials, uint32_t n_part, int Q, int mode, dev_params *__restrict__ P,
+           double *__restrict__ diff_hist, uint32_t hist_cap) {
+    if (mode == 0 && P->stop) return;
+    __shared__ double sacc[BLOCK * (QMAX + 1)];
+    const int tid = threadIdx.x;
+    double acc[QMAX + 1];
+    for (int q = 0; q <= Q; ++q) acc[q] = 0.0;
+    for (uint32_t b = tid; b < n_part; b += BLOCK) {
+        for (int q = 0; q < Q; ++q) acc[q] += partials[size_t(b) * (Q + 1) + q];
+        acc[Q] = nanmax(acc[Q], partials[size_t(b) * (Q + 1) + Q]);
+    }
+    for (int q = 0; q <= Q; ++q) sacc[tid * (QMAX + 1) + q] = acc[q];
+    __syncthreads();
+    for (int s = BLOCK / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            for (int q = 0; q < Q; ++q) sacc[tid * (QMAX + 1) + q] += sacc[(tid + s) * (QMAX + 1) + q];
+            sacc[tid * (QMAX + 1) + Q] = nanmax(sacc[tid * (QMAX + 1) + Q], sacc[(tid + s) * (QMAX + 1) + Q]);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double S[QMAX];
+        const double mix = P->field_mix;
+        for (int q = 0; q < Q; ++q) {
+            double s = sacc[q];
+            if (mode == 0 && P->have_prev && mix < 1.0) s = (1.0 - mix) * P->S[q] + mix * s;
+            S[q] = s;
+            P->S[q] = s;
+        }
+        P->have_prev = 1;
+        for (int q1 = 0; q1 < Q; ++q1) {  // h[q1] = sum_q2 cab[q2][q1] S[q2]   (bp.cpp:341-355)
+            double h = 0.0;
+            for (int q2 = 0; q2 < Q; ++q2) h += P->cab[q2 * Q + q1] * S[q2];
+            const double hN = h * P->invN;
+            P->hN[q1] = hN;
+            P->etaF[q1] = P->eta[q1] * exp(-P->beta * hN);
+        }
+        if (mode == 0) {
+            const double md = sacc[Q];
+            P->maxdiff = md;
+            const int it = P->sweep_idx;
+            if (diff_hist != nullptr && uint32_t(it) < hist_cap) diff_hist[it] = md;
+            if (md < P->crit && P->conv_iter < 0) { P->conv_iter = it; P->stop = 1; }
+            P->sweep_idx = it + 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: site and edge terms of the Bethe free energy and of the entropy, one pass over the frame.
+// partials[b*NP + ...] = { sum_i log Z_i, sum_e log(m_in^T W m_out), e_site numerator sum,
+//                          e_edge sum }                      
+// Hub rows are covered by k_fe_hub.
+// ------------------------------------------------------------------------------------------------
+constexpr int FE_NP = 4;
+
+// edge terms shared by the frame and hub kernels. Wf = weights of f_edge: cab^beta (dc 0),
+// cab (dc 1; the d_i d_l prefactor is a graph constant added on the host), x/(1+x) (dc 2).
+template <int Q, bool DC2>
+__device__ __forceinline__ void edge_terms(const dev_params *__restrict__ P, const double (&mi)[Q], const double (&mo)[Q],
+                                           double didl, double &log_norm, double &ent) {
+    double nl = 0.0, num = 0.0, den = 0.0;
+#pragma unroll
+    for (int q1 = 0; q1 < Q; ++q1) {
+#pragma unroll
+        for (int q2 = 0; q2 < Q; ++q2) {
+            const double pr = mi[q1] * mo[q2];
+            double wf = P->W[q1 * Q + q2];
+            double we = P->cab[q1 * Q + q2];  // entropy uses cab without beta (bp.cpp:628-666)
+            if (DC2) { double x = didl * wf; wf = x / (1.0 + x); we = wf; }
+            nl += wf * pr;
+            den += we * pr;
+            num += we * log(P->cab[q1 * Q + q2]) * pr;
+        }
+    }
+    log_norm = log(nl);
+    ent = num / den;
+}
+
+template <int Q, bool DC2>
+__global__ void __launch_bounds__(BLOCK)
+k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr,
+           const double *__restrict__ M, const uint32_t *__restrict__ blk_row, const dev_params *__restrict__ P,
+           int dc, int want_entropy, double *__restrict__ partials) {
+    constexpr int EPT = frame_cfg<Q>::EPT, CAP = frame_cfg<Q>::CAP, RCAP = frame_cfg<Q>::RCAP;
+    __shared__ double sb[CAP * Q];
+    __shared__ double sc[CAP * Q];  // entropy: b with plain cab weights (no beta)
+    __shared__ uint32_t srp[RCAP + 1];
+    __shared__ uint16_t srow[CAP];
+    __shared__ double sred[4 * (FE_NP + 1)];
+    const int tid = threadIdx.x;
+    const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
+    const int nrows = int(r1 - r0);
+    const uint32_t e0 = row_ptr[r0];
+    for (int r = tid; r <= nrows; r += BLOCK) srp[r] = row_ptr[r0 + r] - e0;
+    __syncthreads();
+    const int ne = int(srp[nrows]);
+    double acc[FE_NP] = {0.0, 0.0, 0.0, 0.0};
+    if (ne <= CAP) {
+        for (int r = tid; r < nrows; r += BLOCK)
+            for (int e = int(srp[r]); e < int(srp[r + 1]); ++e) srow[e] = uint16_t(r);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int le = j * BLOCK + tid;
+            if (le < ne) {
+                double mi[Q], mo[Q], b[Q];
+                load_vec<Q>(M + size_t(rev[e0 + le]) * Q, mi);
+                load_vec<Q>(M + size_t(e0 + le) * Q, mo);
+                double didl = 0.0;
+                if (DC2) {
+                    const int r = srow[le];
+                    const uint32_t l = nbr[e0 + le];
+                    didl = double(srp[r + 1] - srp[r]) * double(row_ptr[l + 1] - row_ptr[l]);
+                }
+                edge_field<Q, DC2>(P, mi, didl, b);
+                store_vec<Q>(&sb[le * Q], b);
+                if (want_entropy) {
+                    double c[Q];
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        double a = 0.0;
+#pragma unroll
+                        for (int t = 0; t < Q; ++t) a += P->cab[t * Q + q] * mi[t];
+                        c[q] = a;
+                    }
+                    store_vec<Q>(&sc[le * Q], c);
+                }
+                double ln, en;
+                edge_terms<Q, DC2>(P, mi, mo, didl, ln, en);
+                acc[1] += ln;
+                if (want_entropy) acc[3] += en;
+            }
+        }
+        __syncthreads();
+        for (int r = tid; r < nrows; r += BLOCK) {
+            const int es = int(srp[r]), ee = int(srp[r + 1]);
+            const double di = double(ee - es);
+            double A[Q];
+            int ex = 0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) A[q] = 1.0;
+            for (int e = es; e < ee; ++e) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) A[q] *= sb[e * Q + q];
+                ex += rescale_pow2<Q>(A);
+            }
+            double tot = 0.0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) tot += A[q] * (dc ? P->eta[q] * exp(-di * P->hN[q]) : P->etaF[q]);
+            acc[0] += log(tot) + double(ex) * 0.6931471805599453;  // log Z_i  (bp.cpp:446-502)
+            if (want_entropy) {  // e_site (bp.cpp:506-560): no beta, weights exp(a + log eta - h/N)
+                double C[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) C[q] = 1.0;
+                for (int e = es; e < ee; ++e) {
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) C[q] *= sc[e * Q + q];
+                    rescale_pow2<Q>(C);
+                }
+                double num = 0.0, den = 0.0;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const double w = C[q] * P->eta[q] * exp(-P->hN[q]);
+                    den += w;
+                    num += w * (-P->hN[q]);
+                }
+                acc[2] += num / den;
+            }
+        }
+    }
+    block_reduce_store<FE_NP>(acc, 0.0, sred, partials + size_t(blockIdx.x) * (FE_NP + 1));
+}
+
+template <int Q, bool DC2>
+__global__ void __launch_bounds__(BLOCK)
+k_fe_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr,
+         const double *__restrict__ M, const uint32_t *__restrict__ hub_row, const uint32_t *__restrict__ hub_blk,
+         const dev_params *__restrict__ P, int dc, int want_entropy, double *__restrict__ partials) {
+    __shared__ double sAq[BLOCK * Q];
+    __shared__ double sCq[BLOCK * Q];
+    __shared__ int sex[BLOCK];
+    __shared__ double sred[4 * (FE_NP + 1)];
+    const int tid = threadIdx.x;
+    const uint32_t i = hub_row[blockIdx.x];
+    const uint32_t e0 = row_ptr[i], d = row_ptr[i + 1] - e0;
+    const double di = double(d);
+    double acc[FE_NP] = {0.0, 0.0, 0.0, 0.0};
+    double A[Q], C[Q];
+    int ex = 0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { A[q] = 1.0; C[q] = 1.0; }
+    for (uint32_t le = tid; le < d; le += BLOCK) {
+        double mi[Q], mo[Q], b[Q];
+        load_vec<Q>(M + size_t(rev[e0 + le]) * Q, mi);
+        load_vec<Q>(M + size_t(e0 + le) * Q, mo);
+        double didl = 0.0;
+        if (DC2) { const uint32_t l = nbr[e0 + le]; didl = di * double(row_ptr[l + 1] - row_ptr[l]); }
+        edge_field<Q, DC2>(P, mi, didl, b);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) A[q] *= b[q];
+        ex += rescale_pow2<Q>(A);
+        if (want_entropy) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                double a = 0.0;
+#pragma unroll
+                for (int t = 0; t < Q; ++t) a += P->cab[t * Q + q] * mi[t];
+                C[q] *= a;
+            }
+            rescale_pow2<Q>(C);
+        }
+        double ln, en;
+        edge_terms<Q, DC2>(P, mi, mo, didl, ln, en);
+        acc[1] += ln;
+        if (want_entropy) acc[3] += en;
+    }
+    store_vec<Q>(&sAq[tid * Q], A);
+    store_vec<Q>(&sCq[tid * Q], C);
+    sex[tid] = ex;
+    __syncthreads();
+    for (int s = BLOCK / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            double o[Q];
+            load_vec<Q>(&sAq[(tid + s) * Q], o);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) A[q] *= o[q];
+            ex += sex[tid + s];
+            ex += rescale_pow2<Q>(A);
+            store_vec<Q>(&sAq[tid * Q], A);
+            sex[tid] = ex;
+            load_vec<Q>(&sCq[(tid + s) * Q], o);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) C[q] *= o[q];
+            rescale_pow2<Q>(C);
+            store_vec<Q>(&sCq[tid * Q], C);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) tot += A[q] * (dc ? P->eta[q] * exp(-di * P->hN[q]) : P->etaF[q]);
+        acc[0] += log(tot) + double(ex) * 0.6931471805599453;
+        if (want_entropy) {
+            double num = 0.0, den = 0.0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const double w = C[q] * P->eta[q] * exp(-P->hN[q]);
+                den += w;
+                num += w * (-P->hN[q]);
+            }
+            acc[2] += num / den;
+        }
+    }
+    block_reduce_store<FE_NP>(acc, 0.0, sred, partials + size_t(hub_blk[blockIdx.x]) * (FE_NP + 1));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4a: per-edge correction of the non-edge terms (adjacent ordered pairs are excluded from the
+// all-pairs moment series): partial[0] = sum_dir log(1 - psi_i^T w psi_l / N),
+// partial[1] = sum_dir (u/N)/(1 - y/N) with u = psi_i^T (cab∘log cab) psi_l, y = psi_i^T cab psi_l.
+// One wave-friendly row loop: lane per row chunk, rows strided; gathers psi_l (N*Q table, cache
+// resident for the sizes where it matters).
+// ------------------------------------------------------------------------------------------------
+constexpr int NE_NP = 2;
+template <int Q>
+__global__ void __launch_bounds__(BLOCK)
+k_nonedge_adj(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, const double *__restrict__ psi,
+              const double *__restrict__ wmat /* Q*Q: N(1-(1-cab/N)^beta) */, const double *__restrict__ cab,
+              const uint32_t *__restrict__ blk_row, double invN, int want_entropy, double *__restrict__ partials) {
+    __shared__ double sred[4 * (NE_NP + 1)];
+    __shared__ uint32_t srp[2 * BLOCK + 1];
+    const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
+    const int nrows = int(r1 - r0);
+    const uint32_t e0 = row_ptr[r0];
+    for (int r = threadIdx.x; r <= nrows; r += BLOCK) srp[r] = row_ptr[r0 + r] - e0;
+    __syncthreads();
+    const int ne = int(srp[nrows]);
+    double acc[NE_NP] = {0.0, 0.0};
+    // lane per directed edge; the row of an edge is found by binary search in the LDS offsets
+    for (int le = threadIdx.x; le < ne; le += BLOCK) {
+        int lo = 0, hi = nrows;  // find r with srp[r] <= le < srp[r+1]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (int(srp[mid]) <= le) lo = mid; else hi = mid; }
+        double pi[Q], pl[Q];
+        load_vec<Q>(psi + size_t(r0 + lo) * Q, pi);
+        load_vec<Q>(psi + size_t(nbr[e0 + le]) * Q, pl);
+        double y = 0.0, yc = 0.0, u = 0.0;
+#pragma unroll
+        for (int q1 = 0; q1 < Q; ++q1) {
+#pragma unroll
+            for (int q2 = 0; q2 < Q; ++q2) {
+                const double pp = pi[q1] * pl[q2];
+                y += wmat[q1 * Q + q2] * pp;
+                if (want_entropy) {
+                    const double c = cab[q1 * Q + q2];
+                    yc += c * pp;
+                    u += c * log(c) * pp;
+                }
+            }
+        }
+        acc[0] += log1p(-y * invN);
+        if (want_entropy) acc[1] += (u * invN) / (1.0 - yc * invN);
+    }
+    block_reduce_store<NE_NP>(acc, 0.0, sred, partials + size_t(blockIdx.x) * (NE_NP + 1));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4b: moment tensors M_k[a_1..a_k] = sum_i prod_j psi_i[a_j], k = 1..K packed back to back
+// (T = Q + Q^2 + ... + Q^K entries). Each workgroup stages a chunk of rows in LDS; thread t owns
+// tensor entries t, t+256, ...; partial tensors per workgroup are folded by k_fold_columns.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK)
+k_moments(const double *__restrict__ psi, uint32_t n_rows, int Q, int K, uint32_t rows_per_blk, int T,
+          double *__restrict__ partials /* [gridDim.x][T] */) {
+    __shared__ double sp[BLOCK * QMAX];
+    const int tid = threadIdx.x;
+    constexpr int MAXE = 20;  // entries per thread: T <= 256*20 = 5120 >= 8+64+512+4096
+    double acc[MAXE];
+    for (int j = 0; j < MAXE; ++j) acc[j] = 0.0;
+    const uint32_t lo = blockIdx.x * rows_per_blk, hi = min(n_rows, lo + rows_per_blk);
+    for (uint32_t base = lo; base < hi; base += BLOCK) {
+        const uint32_t cnt = min(uint32_t(BLOCK), hi - base);
+        __syncthreads();
+        for (uint32_t x = tid; x < cnt * Q; x += BLOCK) sp[x] = psi[size_t(base) * Q + x];
+        __syncthreads();
+        int j = 0;
+        for (int ent = tid; ent < T; ent += BLOCK, ++j) {
+            // decode (order k, multi-index) of the packed entry
+            int k = 1, off = 0, sz = Q;
+            while (ent >= off + sz) { off += sz; sz *= Q; ++k; }
+            int idx = ent - off;
+            int a[4];
+            for (int t = 0; t < 4; ++t) { a[t] = idx % Q; idx /= Q; }
+            double s = 0.0;
+            for (uint32_t r = 0; r < cnt; ++r) {
+                const double *p = &sp[r * Q];
+                double v = p[a[0]];
+                if (k > 1) v *= p[a[1]];
+                if (k > 2) v *= p[a[2]];
+                if (k > 3) v *= p[a[3]];
+                s += v;
+            }
+            acc[j] += s;
+        }
+    }
+    int j = 0;
+    for (int ent = tid; ent < T; ent += BLOCK, ++j) partials[size_t(blockIdx.x) * T + ent] = acc[j];
+}
+
+// column sums of a [rows][cols] partial matrix in fixed order: out[c] = sum_r in[r][c]
+__global__ void __launch_bounds__(BLOCK)
+k_fold_columns(const double *__restrict__ in, uint32_t rows, uint32_t cols, double *__restrict__ out) {
+    const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= cols) return;
+    double s = 0.0;
+    for (uint32_t r = 0; r < rows; ++r) s += in[size_t(r) * cols + c];
+    out[c] = s;
+}
+// sticky-NaN column max companion (used for the max slot of frame partials)
+__global__ void __launch_bounds__(BLOCK)
+k_fold_rows_sum(const double *__restrict__ in, uint32_t rows, uint32_t cols, uint32_t stride, double *__restrict__ out) {
+    // out[c] = sum over rows of in[r*stride + c], c < cols; one workgroup, fixed order
+    __shared__ double s[BLOCK];
+    for (uint32_t c = 0; c < cols; ++c) {
+        double a = 0.0;
+        for (uint32_t r = threadIdx.x; r < rows; r += BLOCK) a += in[size_t(r) * stride + c];
+        s[threadIdx.x] = a;
+        __syncthreads();
+        for (int k = BLOCK / 2; k > 0; k >>= 1) {
+            if (int(threadIdx.x) < k) s[threadIdx.x] += s[threadIdx.x + k];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[c] = s[0];
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4x: exact non-edge sums over ALL ordered pairs (i,l) — the reference's O(N^2) loop
+// (belief_propagation.cpp:675-741) as a tiled kernel; the adjacent pairs are removed afterwards
+// with k_nonedge_adj. Tile = 256 rows i (one per lane) x 256 rows l staged in LDS.
+// partial[0] = sum log(psi_i^T P psi_l), P = (1-cab/N)^beta;  partial[1] = sum num/den (entropy).
+// ------------------------------------------------------------------------------------------------
+template <int Q>
+__global__ void __launch_bounds__(BLOCK)
+k_nonedge_exact(const double *__restrict__ psi, uint32_t n, const double *__restrict__ Pmat /* Q*Q */,
+                const double *__restrict__ cab, double invN, int want_entropy, double *__restrict__ partials) {
+    __shared__ double sl[BLOCK * Q];
+    __shared__ double sred[4 * (NE_NP + 1)];
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t l0 = blockIdx.y * BLOCK;
+    const uint32_t cnt = min(uint32_t(BLOCK), n - l0);
+    for (uint32_t x = threadIdx.x; x < cnt * Q; x += BLOCK) sl[x] = psi[size_t(l0) * Q + x];
+    __syncthreads();
+    double acc[NE_NP] = {0.0, 0.0};
+    if (i < n) {
+        double pi[Q], v[Q], vn[Q], vd[Q];
+        load_vec<Q>(psi + size_t(i) * Q, pi);
+#pragma unroll
+        for (int q2 = 0; q2 < Q; ++q2) {  // v = P^T psi_i etc., so a pair costs Q FMAs
+            double a = 0.0, an = 0.0, ad = 0.0;
+#pragma unroll
+            for (int q1 = 0; q1 < Q; ++q1) {
+                a += Pmat[q1 * Q + q2] * pi[q1];
+                if (want_entropy) {
+                    const double c = cab[q1 * Q + q2];
+                    an += (c * invN) * log(c) * pi[q1];
+                    ad += (1.0 - c * invN) * pi[q1];
+                }
+            }
+            v[q2] = a; vn[q2] = an; vd[q2] = ad;
+        }
+        for (uint32_t r = 0; r < cnt; ++r) {
+            double f = 0.0, num = 0.0, den = 0.0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const double pl = sl[r * Q + q];
+                f += v[q] * pl;
+                if (want_entropy) { num += vn[q] * pl; den += vd[q] * pl; }
+            }
+            if (f != 0.0) acc[0] += log(f);
+            if (want_entropy && num * den != 0.0) acc[1] += num / den;
+        }
+    }
+    block_reduce_store<NE_NP>(acc, 0.0, sred, partials + (size_t(blockIdx.y) * gridDim.x + blockIdx.x) * (NE_NP + 1));
+}
+
+// exact per-edge terms to subtract from the all-pairs sums of k_nonedge_exact
+template <int Q>
+__global__ void __launch_bounds__(BLOCK)
+k_nonedge_exact_adj(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, const double *__restrict__ psi,
+                    const double *__restrict__ Pmat, const double *__restrict__ cab, const uint32_t *__restrict__ blk_row,
+                    double invN, int want_entropy, double *__restrict__ partials) {
+    __shared__ double sred[4 * (NE_NP + 1)];
+    __shared__ uint32_t srp[2 * BLOCK + 1];
+    const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
+    const int nrows = int(r1 - r0);
+    const uint32_t e0 = row_ptr[r0];
+    for (int r = threadIdx.x; r <= nrows; r += BLOCK) srp[r] = row_ptr[r0 + r] - e0;
+    __syncthreads();
+    const int ne = int(srp[nrows]);
+    double acc[NE_NP] = {0.0, 0.0};
+    for (int le = threadIdx.x; le < ne; le += BLOCK) {
+        int lo = 0, hi = nrows;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (int(srp[mid]) <= le) lo = mid; else hi = mid; }
+        double pi[Q], pl[Q];
+        load_vec<Q>(psi + size_t(r0 + lo) * Q, pi);
+        load_vec<Q>(psi + size_t(nbr[e0 + le]) * Q, pl);
+        double f = 0.0, num = 0.0, den = 0.0;
+#pragma unroll
+        for (int q1 = 0; q1 < Q; ++q1) {
+#pragma unroll
+            for (int q2 = 0; q2 < Q; ++q2) {
+                const double pp = pi[q1] * pl[q2];
+                f += Pmat[q1 * Q + q2] * pp;
+                if (want_entropy) {
+                    const double c = cab[q1 * Q + q2];
+                    num += (c * invN) * log(c) * pp;
+                    den += (1.0 - c * invN) * pp;
+                }
+            }
+        }
+        if (f != 0.0) acc[0] += log(f);
+        if (want_entropy && num * den != 0.0) acc[1] += num / den;
+    }
+    block_reduce_store<NE_NP>(acc, 0.0, sred, partials + size_t(blockIdx.x) * (NE_NP + 1));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: EM expectation numerators (belief_propagation.cpp:892-965): per directed edge
+// 0.5 * W'[q1][q2] * (m_in[q1] m_out[q2] + [q1!=q2] m_in[q2] m_out[q1]) / norm_L for q1 <= q2,
+// accumulated per lane over a grid-stride loop, then folded. Output row per workgroup: Q*Q entries
+// (upper triangle filled). W' = cab (dc 0, no beta), cab (dc 1: prefactor cancels), x/(1+x) (dc 2).
+// ------------------------------------------------------------------------------------------------
+template <int Q, bool DC2>
+__global__ void __launch_bounds__(BLOCK)
+k_em_edges(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr,
+           const uint32_t *__restrict__ src /* row of each edge, DC2 only */, const double *__restrict__ M,
+           uint32_t n_edges, const dev_params *__restrict__ P, double *__restrict__ partials /* [grid][Q*Q] */) {
+    constexpr int T = Q * (Q + 1) / 2;
+    __shared__ double sred[4 * (T + 1)];
+    double acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = 0.0;
+    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < n_edges; k += gridDim.x * BLOCK) {
+        double mi[Q], mo[Q];
+        load_vec<Q>(M + size_t(rev[k]) * Q, mi);
+        load_vec<Q>(M + size_t(k) * Q, mo);
+        double didl = 0.0;
+        if (DC2) {
+            const uint32_t i = src[k], l = nbr[k];
+            didl = double(row_ptr[i + 1] - row_ptr[i]) * double(row_ptr[l + 1] - row_ptr[l]);
+        }
+        double term[T], norm_L = 0.0;
+        int t = 0;
+#pragma unroll
+        for (int q1 = 0; q1 < Q; ++q1) {
+#pragma unroll
+            for (int q2 = q1; q2 < Q; ++q2, ++t) {
+                double w = P->cab[q1 * Q + q2];
+                if (DC2) { double x = didl * w * P->invN; w = x / (1.0 + x); }
+                const double pr = (q1 == q2) ? (mi[q1] * mo[q2]) : (mi[q1] * mo[q2] + mi[q2] * mo[q1]);
+                term[t] = w * pr;
+                norm_L += term[t];
+            }
+        }
+        const double inv = 0.5 / norm_L;
+#pragma unroll
+        for (int u = 0; u < T; ++u) acc[u] += term[u] * inv;
+    }
+    block_reduce_store<T>(acc, 0.0, sred, partials + size_t(blockIdx.x) * (T + 1));
+}
+
+// K5b/K6: per-row sums: na_expect, nna_expect (belief_propagation.cpp:428-440) and the confusion
+// matrix C[a][b] = sum_{i: true_i = a} psi_i[b] (compute_overlap, :775-811). Row chunk per workgroup,
+// LDS accumulation by (class, label) with one owner thread per output entry.
+template <int Q>
+__global__ void __launch_bounds__(BLOCK)
+k_row_sums(const uint32_t *__restrict__ row_ptr, const double *__restrict__ psi, const uint32_t *__restrict__ true_conf,
+           uint32_t n_rows, uint32_t rows_per_blk, double *__restrict__ partials /* [grid][2Q + Q*Q] */) {
+    __shared__ double sp[BLOCK * Q];
+    __shared__ uint32_t sdeg[BLOCK];
+    __shared__ uint32_t scl[BLOCK];
+    constexpr int T = 2 * Q + Q * Q;
+    const int tid = threadIdx.x;
+    double acc = 0.0;  // thread t < T owns output entry t
+    const uint32_t lo = blockIdx.x * rows_per_blk, hi = min(n_rows, lo + rows_per_blk);
+    for (uint32_t base = lo; base < hi; base += BLOCK) {
+        const uint32_t cnt = min(uint32_t(BLOCK), hi - base);
+        __syncthreads();
+        for (uint32_t x = tid; x < cnt * Q; x += BLOCK) sp[x] = psi[size_t(base) * Q + x];
+        if (uint32_t(tid) < cnt) {
+            sdeg[tid] = row_ptr[base + tid + 1] - row_ptr[base + tid];
+            scl[tid] = true_conf ? true_conf[base + tid] : 0u;
+        }
+        __syncthreads();
+        if (tid < Q) {
+            for (uint32_t r = 0; r < cnt; ++r) acc += sp[r * Q + tid];
+        } else if (tid < 2 * Q) {
+            for (uint32_t r = 0; r < cnt; ++r) acc += double(sdeg[r]) * sp[r * Q + (tid - Q)];
+        } else if (tid < T) {
+            const uint32_t a = uint32_t(tid - 2 * Q) / Q, b = uint32_t(tid - 2 * Q) % Q;
+            for (uint32_t r = 0; r < cnt; ++r) acc += (scl[r] == a) ? sp[r * Q + b] : 0.0;
+        }
+    }
+    if (tid < T) partials[size_t(blockIdx.x) * T + tid] = acc;
+}
+
+// row index of every directed edge (built once; used by reductions that need d_i per edge)
+__global__ void __launch_bounds__(BLOCK)
+k_fill_src(const uint32_t *__restrict__ row_ptr, uint32_t n_rows, uint32_t *__restrict__ src) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_rows) return;
+    for (uint32_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) src[k] = i;
+}
+
+// counter-based initial state: splitmix64 of (seed, slot) -> uniform(0,1), normalised per Q-vector
+__device__ __forceinline__ double u01(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double(z >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+__global__ void __launch_bounds__(BLOCK)
+k_init_random(double *__restrict__ v, uint64_t n_vec, int Q, uint64_t seed, uint64_t salt) {
+    const uint64_t i = uint64_t(blockIdx.x) * BLOCK + threadIdx.x;
+    if (i >= n_vec) return;
+    double t[QMAX], norm = 0.0;
+    for (int q = 0; q < Q; ++q) { t[q] = u01(seed ^ salt, i * uint64_t(Q) + q); norm += t[q]; }
+    for (int q = 0; q < Q; ++q) v[i * Q + q] = t[q] / norm;
+}
+
+}  // namespace sbmbp
+#endif

@@ -1,0 +1,134 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/sbmbp.h declares, and the
+host-side logic behind it (CSR builder, edge-list parser, parameter constructors) agrees with
+the oracle. No compute entry point is called here (no GPU in this tier)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT, args_of, golden, gpath
+
+
+@pytest.fixture(scope="module")
+def S():
+    import sbm_bp_amd as S
+    S.build_all()
+    S.load_library()
+    return S
+
+
+def test_every_declared_symbol_is_exported_and_bound(S):
+    from sbm_bp_amd.capi import SYMBOLS
+    hdr = open(os.path.join(ROOT, "include", "sbmbp.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sbmbp_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(SYMBOLS), (declared ^ set(SYMBOLS))
+    raw = C.CDLL(S.lib_path())
+    for name in declared:
+        assert getattr(raw, name) is not None
+
+
+def test_header_is_plain_c():
+    import shutil
+    import subprocess
+    import tempfile
+    cc = shutil.which("gcc")
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        open(src, "w").write('#include "sbmbp.h"\nint main(void){return sizeof(sbmbp_stats) > 0 ? 0 : 1;}\n')
+        subprocess.check_call([cc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", src, "-o",
+                               os.path.join(d, "t.o")])
+
+
+def test_error_strings_and_no_device_failure(S):
+    lib = S.load_library()
+    assert lib.sbmbp_strerror(0) == b"ok"
+    assert b"GPU" in lib.sbmbp_strerror(-3)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    g = S.load_edge_list(gpath("c1_dataset.edgelist"), 1000)
+    bp = S.bp_conditional()
+    with pytest.raises(S.SbmbpError) as ei:  # the product path fails loudly, it never falls back to a CPU path
+        bp.init_messages(S.blockmodel_t(g, 2, 0), 0, None, np.repeat([0, 1], 500), 0)
+    assert ei.value.code == -3
+
+
+def test_csr_builder_equals_oracle_on_dataset(S, orc):
+    g = S.load_edge_list(gpath("c1_dataset.edgelist"), 1000)
+    og = orc.Graph.from_edgelist(gpath("c1_dataset.edgelist"), 1000)
+    rp, nbr, rev = g.csr()
+    assert (g.N, g.E2, g.max_degree) == (1000, 2996, 10)
+    assert (rp == og.row_ptr).all() and (nbr == og.nbr).all() and (rev == og.rev).all()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_csr_builder_random_multigraph(S, orc, seed):
+    rng = np.random.default_rng(seed)
+    N = 300
+    pairs = rng.integers(0, N, size=(2000, 2)).astype(np.uint32)  # duplicates, reversed duplicates, self-loops
+    g = S.Graph.from_edges(pairs, N)
+    og = orc.Graph.from_edges(pairs, N)
+    rp, nbr, rev = g.csr()
+    assert (rp == og.row_ptr).all() and (nbr == og.nbr).all() and (rev == og.rev).all()
+    assert (rev[rev] == np.arange(g.E2)).all()
+    g2 = S.Graph.from_csr(rp, nbr)  # adopting a CSR recomputes the same reverse index
+    assert (g2.csr()[2] == rev).all()
+    with pytest.raises(S.SbmbpError):
+        bad = nbr.copy()
+        bad[0] = (bad[0] + 1) % N
+        S.Graph.from_csr(rp, bad)
+
+
+def test_empty_and_ragged_graphs(S, orc):
+    g = S.Graph.from_edges(np.zeros((0, 2), dtype=np.uint32), 5)
+    assert (g.N, g.E2, g.max_degree) == (5, 0, 0)
+    g = S.Graph.from_edges([[0, 9]], 3)  # ids beyond N grow the graph (graph_utilities.cpp:65-72)
+    assert g.N == 10 and g.E2 == 2
+    star = np.array([[0, i] for i in range(1, 2000)], dtype=np.uint32)  # one hub, many leaves
+    g = S.Graph.from_edges(star, 2000)
+    assert g.max_degree == 1999 and g.E2 == 2 * 1999
+
+
+def test_edgelist_parser_errors(S, tmp_path):
+    p = tmp_path / "ok.edgelist"
+    p.write_text("0 1\n\n2 3 0.5\n 4\t5 \r\n")
+    g = S.load_edge_list(str(p), 0)
+    assert g.N == 6 and g.E2 == 6
+    for bad in ("0 1\n7\n", "0 x\n", "a b\n"):
+        q = tmp_path / "bad.edgelist"
+        q.write_text(bad)
+        with pytest.raises(S.SbmbpError):
+            S.load_edge_list(str(q), 0)
+    with pytest.raises(S.SbmbpError) as ei:
+        S.load_edge_list(str(tmp_path / "missing.edgelist"), 10)
+    assert ei.value.code == -5  # documented deviation: the reference yields an empty graph
+
+
+def test_param_constructors_equal_oracle_and_golden(S, orc):
+    for name in ("c1_matched_tight_seed0", "q4_tight_seed0", "q4_epsc_default_seed0", "hub_dc0_tight_seed0"):
+        gd = golden(name)
+        a, r = args_of(gd), gd["result"]
+        g = S.load_edge_list(a["path"], a["N"])
+        bm = S.blockmodel_t(g, a["Q"], a["dc"])
+        st = S.bp_param_from_epsilon_c(bm, a["eps"], a["c"]) if "eps" in a else S.bp_param_from_direct(bm, a["pa"], a["cab_upper"])
+        assert list(st.cab.ravel()) == r["cab"] and list(st.na) == r["na"]
+    bm = S.blockmodel_t(S.Graph.from_edges([[0, 1]], 1001), 3, 0)  # truncation quirk B7: na does not sum to N
+    assert list(S.bp_param_from_epsilon_c(bm, 0.1, 3.0).na) == [333, 333, 333]
+    st = S.bp_param_from_epsilon_c(bm, -1.0, 3.0)  # epsilon < 0: fully disassortative (blockmodel.cpp:251-254)
+    assert st.cab[0, 0] == 0 and abs(st.cab[0, 1] - 4.5) < 1e-15
+
+
+def test_synthetic_generator(S):
+    from sbm_bp_amd import synth
+    pairs, cin, cout = synth.planted_partition(40000, 4, 10.0, 0.1, 7)
+    assert abs(cin - 40 / 1.3) < 1e-12 and abs(cout - 0.1 * cin) < 1e-12
+    assert (pairs[:, 0] < pairs[:, 1]).all()
+    mean_deg = 2 * len(pairs) / 40000
+    assert abs(mean_deg - 10.0) < 0.2
+    tc = synth.true_conf(40000, 4)
+    same = (tc[pairs[:, 0]] == tc[pairs[:, 1]]).mean()
+    assert abs(same - cin / (cin + 3 * cout)) < 0.01

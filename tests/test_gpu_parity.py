@@ -1,0 +1,288 @@
+"""Parity of the HIP engine (through the C ABI) against the oracle and the committed reference
+goldens. Floating point: the engine must land on the reference's fixed point; tolerances are the
+north star's 1e-5 relative, tightened to what fp64 actually delivers (stated per assert)."""
+import numpy as np
+import pytest
+
+from conftest import args_of, best_perm_diff, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    import sbm_bp_amd as S
+    S.load_library()
+    return S
+
+
+def engine_from(S, a, learn=False, seed=None):
+    g = S.load_edge_list(a["path"], a["N"])
+    bm = S.blockmodel_t(g, a["Q"], a["dc"])
+    bp = S.bp_basic() if learn else S.bp_conditional()
+    bp.init_messages(bm, a["init_flag"], a.get("beliefs"), a["true_conf"], a["seed"] if seed is None else seed)
+    bp.set_beta(a["beta"])
+    if "eps" in a:
+        st = S.bp_param_from_epsilon_c(bm, a["eps"], a["c"])
+    else:
+        st = S.bp_param_from_direct(bm, a["pa"], a["cab_upper"])
+    bp.expand_bp_params(st)
+    return g, bm, bp, st
+
+
+def oracle_from(orc, a):
+    g = orc.Graph.from_edgelist(a["path"], a["N"])
+    bp = orc.OracleBP(g, a["Q"], a["dc"])
+    rng = orc.Rng(a["seed"])
+    bp.init_messages(a["init_flag"], a.get("beliefs"), a["true_conf"], rng)
+    if "eps" in a:
+        cab, na = orc.param_from_epsilon_c(a["N"], a["Q"], a["eps"], a["c"])
+    else:
+        cab, na = orc.param_from_direct(a["N"], a["Q"], a["pa"], a["cab_upper"])
+    bp.set_params(cab, na, a["beta"])
+    return g, bp, rng
+
+
+TIGHT = ["c1_matched_tight_seed0", "c1_matched_beta08_seed0", "c1_dc1_tight_seed0", "c1_dc2_tight_seed0",
+         "q4_tight_seed0", "c1_planted_i1_seed0", "hub_dc1_tight_seed0"]
+
+
+@pytest.mark.parametrize("name", TIGHT + ["hub_dc0_tight_seed0"])
+def test_initial_state_is_the_reference_rng_stream(S, orc, name):
+    a = args_of(golden(name))
+    _, _, bp, _ = engine_from(S, a)
+    _, obp, _ = oracle_from(orc, a)
+    psi, msg = bp.get_state()
+    opsi, omsg = obp.get_state()
+    assert (psi == opsi).all() and (msg == omsg).all()  # bit-exact: same mt19937 draws, same fill order
+
+
+@pytest.mark.parametrize("name", TIGHT + ["hub_dc0_tight_seed0"])
+def test_sweeps_match_the_synchronous_oracle(S, orc, name):
+    a = args_of(golden(name))
+    _, _, bp, _ = engine_from(S, a)
+    _, obp, _ = oracle_from(orc, a)
+    for sweep in range(3):
+        d_gpu = bp.sweep(1, 1.0)
+        d_cpu = obp.sweep_sync(1.0)
+        psi, msg = bp.get_state()
+        opsi, omsg = obp.get_state()
+        assert np.abs(msg - omsg).max() < 1e-12, "messages after sweep %d" % sweep
+        assert np.abs(psi - opsi).max() < 1e-12
+        assert abs(d_gpu - d_cpu) < 1e-12
+    assert np.abs(msg.sum(1) - 1).max() < 1e-14 and np.abs(psi.sum(1) - 1).max() < 1e-14
+
+
+def test_damped_sweeps_match_the_oracle(S, orc):
+    a = args_of(golden("c1_matched_damped_seed0"))
+    _, _, bp, _ = engine_from(S, a)
+    _, obp, _ = oracle_from(orc, a)
+    for _ in range(4):
+        d_gpu, d_cpu = bp.sweep(1, 0.5), obp.sweep_sync(0.5)
+        assert abs(d_gpu - d_cpu) < 1e-12
+    assert np.abs(bp.get_state()[1] - obp.get_state()[1]).max() < 1e-12
+
+
+@pytest.mark.parametrize("name", TIGHT)
+def test_converged_fixed_point_equals_reference_golden(S, name):
+    gd = golden(name)
+    a, r = args_of(gd), gd["result"]
+    _, _, bp, _ = engine_from(S, a)
+    niter, last = bp.converge(1e-13, 5000, 1.0)
+    assert niter >= 0 and last < 1e-13
+    psi = bp.real_psi()
+    d, _ = best_perm_diff(psi, np.array(r["psi"]).reshape(psi.shape))
+    assert d < 1e-9  # marginals modulo label permutation; north star asks 1e-5 relative
+    f, parts = bp.compute_free_energy(parts=True)
+    assert abs(f - r["f"]) <= 1e-9 * max(1.0, abs(r["f"]))  # north star: 1e-5 relative
+    for got, key in zip(parts, ("f_site", "f_edge", "f_nonedge")):
+        assert abs(got - r[key]) <= 1e-9 * max(1.0, abs(r[key]))
+    assert abs(bp.compute_overlap() - r["overlap"]) < 1e-9
+    e, eparts = bp.compute_entropy(parts=True)
+    if np.isnan(r["e"]):
+        assert np.isnan(e)  # reference prints -nan for deg_corr_flag != 0
+    else:
+        assert abs(e - r["e"]) <= 1e-9 * max(1.0, abs(r["e"]))
+        for got, key in zip(eparts, ("e_site", "e_edge", "e_nonedge")):
+            assert abs(got - r[key]) <= 1e-9 * max(1.0, abs(r[key]))
+
+
+def test_field_relaxation_reaches_reference_fixed_point_on_hub_graph(S):
+    """plain SBM on a power-law graph: pure Jacobi oscillates through the lagged global field;
+    field_mix 0.1 converges to the fixed point of the reference's asynchronous run."""
+    gd = golden("hub_dc0_tight_seed0")
+    a, r = args_of(gd), gd["result"]
+    _, _, bp, _ = engine_from(S, a)
+    niter, last = bp.converge(1e-13, 300, 1.0)
+    assert niter == -1 and last > 0.1  # period-2 oscillation without relaxation
+    _, _, bp, _ = engine_from(S, a)
+    bp.set_schedule(field_mix=0.1, check_every=8)
+    niter, last = bp.converge(1e-13, 5000, 1.0)
+    assert niter >= 0
+    psi = bp.real_psi()
+    d, _ = best_perm_diff(psi, np.array(r["psi"]).reshape(psi.shape))
+    assert d < 1e-9
+    f = bp.compute_free_energy()
+    assert abs(f - r["f"]) <= 1e-9 * abs(r["f"])
+
+
+def test_niter_and_batched_convergence_check_agree_with_oracle(S, orc):
+    a = args_of(golden("c1_matched_default_seed0"))
+    _, obp, _ = oracle_from(orc, a)
+    it_cpu, _ = obp.converge_sync(a["crit"], a["tmax"], 1.0)
+    for every in (1, 7):
+        _, _, bp, _ = engine_from(S, a)
+        bp.set_schedule(1.0, every)
+        it_gpu, _ = bp.converge(a["crit"], a["tmax"], 1.0)
+        assert it_gpu == it_cpu  # the device-side stop flag makes niter independent of the batch size
+        assert np.abs(bp.get_state()[1] - obp.get_state()[1]).max() < 1e-11
+    # the reference's asynchronous niter for this run is 56; sync needs a comparable number
+    assert abs(it_gpu - golden("c1_matched_default_seed0")["result"]["niter"]) <= 10
+
+
+def test_readme_infer_line(S):
+    """README.md:36 command: stdout `2.99556 -0.143476 0.5 <niter>` (niter is schedule dependent)"""
+    gd = golden("c1_readme_infer_seed0")
+    a, r = args_of(gd), gd["result"]
+    g, bm, bp, st = engine_from(S, a)
+    res = bp.inference(bm, st, a["crit"], a["tmax"], a["damp"])
+    from sbm_bp_amd.bp import format_infer_line
+    line = format_infer_line(res).split()
+    assert line[:2] == ["2.99556", "-0.143476"] and len(line) == 4
+    # at the loose default criterion 5e-6 both codes sit within ~criterion of the fixed point
+    assert abs(res.overlap - r["overlap"]) < 1e-5
+    assert abs(res.free_energy - r["f"]) < 1e-6 and abs(res.entropy - r["e"]) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["c1_em_expect_seed0", "c1_em_expect_dc1_seed0", "c1_em_expect_dc2_seed0", "q4_em_expect_seed0"])
+def test_em_expectations_on_fixed_point(S, name):
+    gd = golden(name)
+    a, r = args_of(gd), gd["result"]
+    _, _, bp, _ = engine_from(S, a, learn=True)
+    niter, _ = bp.converge(1e-13, 5000, 1.0)
+    assert niter >= 0
+    na, nna, cab = bp.em_expectations()
+    Q = a["Q"]
+    ref_na, ref_nna, ref_cab = np.array(r["na_expect"]), np.array(r["nna_expect"]), np.array(r["cab_expect"]).reshape(Q, Q)
+    import itertools
+    best = min(itertools.permutations(range(Q)), key=lambda p: np.abs(na[list(p)] - ref_na).max())
+    p = list(best)
+    assert np.abs(na[p] - ref_na).max() < 1e-7 and np.abs(nna[p] - ref_nna).max() < 1e-6
+    assert np.abs(cab[np.ix_(p, p)] - ref_cab).max() < 1e-8 * max(1.0, np.abs(ref_cab).max())
+
+
+@pytest.mark.parametrize("name", ["c1_learn_515_seed0", "q4_learn_seed2"])
+def test_learning_matches_synchronous_oracle(S, orc, name):
+    """EM trajectories depend on the schedule; the engine must follow the oracle's synchronous EM run
+    step for step and end near the reference's (asynchronous) learned parameters."""
+    gd = golden(name)
+    a, r = args_of(gd), gd["result"]
+    g, bm, bp, st = engine_from(S, a, learn=True)
+    res = bp.learning(bm, st, a["lcrit"], a["tmax"], a["lr"], a["damp"])
+    _, obp, _ = oracle_from(orc, a)
+    steps, f = obp.learning(a["lcrit"], a["tmax"], a["lr"], a["damp"], None, sync=True, series_K=0)
+    cab, na = bp.get_params()
+    ocab, ona = obp.get_params()
+    assert res.em_steps == steps and list(na) == list(ona)
+    assert np.abs(cab - ocab).max() < 1e-8 and abs(res.free_energy - f) < 1e-9
+    if name.startswith("c1_"):
+        # well-posed start: the synchronous EM run ends next to the reference's asynchronous one. (From a
+        # poor start — q4_learn_seed2 — EM is trajectory dependent and the schedules reach different
+        # local optima; there only the oracle parity above is meaningful.)
+        ref_cab = np.array(r["cab_final"]).reshape(cab.shape)
+        assert np.abs(np.sort(np.diag(cab)) - np.sort(np.diag(ref_cab))).max() < 5e-2 * np.abs(ref_cab).max()
+        assert abs(res.overlap - r["overlap"]) < 2e-2
+
+
+def test_series_and_exact_nonedge_agree(S):
+    a = args_of(golden("c1_matched_tight_seed0"))
+    _, _, bp, _ = engine_from(S, a)
+    bp.converge(1e-12, 2000, 1.0)
+    bp.set_nonedge_mode(1, 0)
+    f_exact, p_exact = bp.compute_free_energy(parts=True)
+    e_exact, q_exact = bp.compute_entropy(parts=True)
+    bp.set_nonedge_mode(2, 4)
+    f_ser, p_ser = bp.compute_free_energy(parts=True)
+    e_ser, q_ser = bp.compute_entropy(parts=True)
+    assert abs(p_exact[2] - p_ser[2]) < 1e-9  # K=4 at N=1000 leaves 1.3e-10
+    assert abs(q_exact[2] - q_ser[2]) < 1e-8
+
+
+def _synthetic(S, orc, N, Q, c, eps, seed, dc=0):
+    from sbm_bp_amd import synth
+    pairs, cin, cout = synth.planted_partition(N, Q, c, eps, seed)
+    g = S.Graph.from_edges(pairs, N)
+    og = orc.Graph.from_edges(pairs, N)
+    return g, og, synth.cab_matrix(Q, cin, cout), synth.true_conf(N, Q)
+
+
+@pytest.mark.parametrize("N,Q,c", [(20000, 2, 3.0), (20000, 4, 10.0), (6000, 8, 12.0), (5000, 3, 6.0), (5000, 5, 8.0)])
+def test_synthetic_graphs_sweeps_and_reductions(S, orc, N, Q, c):
+    g, og, cab, tc = _synthetic(S, orc, N, Q, c, 0.1, 3)
+    rp, nbr, rev = g.csr()
+    assert (rp == og.row_ptr).all() and (nbr == og.nbr).all() and (rev == og.rev).all()
+    na = np.array([N // Q] * Q, dtype=np.uint32)
+    bm = S.blockmodel_t(g, Q, 0)
+    bp = S.bp_conditional()
+    bp.init_messages(bm, 0, None, tc, 5)
+    bp.expand_bp_params(S.bp_blockmodel_state(cab, na))
+    obp = orc.OracleBP(og, Q, 0)
+    obp.init_messages(0, None, tc, orc.Rng(5))
+    obp.set_params(cab, na, 1.0)
+    for _ in range(5):
+        assert abs(bp.sweep(1, 1.0) - obp.sweep_sync(1.0)) < 1e-12
+    psi, msg = bp.get_state()
+    opsi, omsg = obp.get_state()
+    assert np.abs(msg - omsg).max() < 1e-12 and np.abs(psi - opsi).max() < 1e-12
+    obp.compute_h()
+    f, parts = bp.compute_free_energy(parts=True)
+    of, oparts = obp.free_energy(0 if N <= 20000 else 3)
+    assert np.abs(parts - oparts).max() < 1e-10 * max(1.0, np.abs(oparts).max())
+    na_e, nna_e, cab_e = bp.em_expectations()
+    ona, onna, ocab = obp.em_expect()
+    assert np.abs(na_e - ona).max() < 1e-8 and np.abs(cab_e - ocab).max() < 1e-9 * max(1.0, np.abs(ocab).max())
+    assert abs(bp.compute_overlap() - obp.overlap()) < 1e-12
+
+
+def test_full_size_properties_c2(S):
+    """BASELINE config C2 (N=1e6, Q=2, c=3) through size-independent properties: normalisation,
+    label-permutation equivariance, monotone approach to the fixed point, reproducibility."""
+    from sbm_bp_amd import synth
+    N, Q = 1000000, 2
+    pairs, cin, cout = synth.planted_partition(N, Q, 3.0, 0.1, 1)
+    g = S.Graph.from_edges(pairs, N)
+    tc = synth.true_conf(N, Q)
+    cab = synth.cab_matrix(Q, cin, cout)
+    na = np.array([N // Q] * Q, dtype=np.uint32)
+    bm = S.blockmodel_t(g, Q, 0)
+    outs = []
+    for rep in range(2):
+        bp = S.bp_conditional()
+        bp.init_messages_device(bm, tc, 42)
+        bp.expand_bp_params(S.bp_blockmodel_state(cab, na))
+        diffs = [bp.sweep(1, 1.0) for _ in range(12)]
+        psi, msg = bp.get_state()
+        outs.append((psi, msg, diffs))
+    assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()  # bitwise reproducible
+    psi, msg, diffs = outs[0]
+    assert np.abs(msg.sum(1) - 1).max() < 1e-14 and np.abs(psi.sum(1) - 1).max() < 1e-14
+    assert msg.min() >= 0 and np.isfinite(msg).all()
+    # label permutation: swapping the two labels of the initial state and of cab swaps the result
+    bp = S.bp_conditional()
+    bp.init_messages_device(bm, tc, 42)
+    p0, m0 = bp.get_state()
+    bp.set_state(p0[:, ::-1].copy(), m0[:, ::-1].copy())
+    bp.expand_bp_params(S.bp_blockmodel_state(cab[::-1, ::-1].copy(), na[::-1].copy()))
+    for _ in range(12):
+        bp.sweep(1, 1.0)
+    p1, m1 = bp.get_state()
+    assert np.abs(p1[:, ::-1] - psi).max() < 1e-12 and np.abs(m1[:, ::-1] - msg).max() < 1e-12
+    st = bp.stats()
+    assert st.edge_msg_updates == 12 * g.E2
+    # the run converges at the default criterion and detects the planted groups (C1-like parameters: ~0.84)
+    bp.set_schedule(1.0, 8)
+    niter, last = bp.converge(5e-6, 1000, 1.0)
+    assert niter >= 0 and last < 5e-6
+    assert 0.80 < bp.compute_overlap() < 0.88
+    f = bp.compute_free_energy()
+    assert np.isfinite(f)
