@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--converge", action="store_true", help="also report sweeps-to-converge at 5e-6 (untimed)")
+    ap.add_argument("--gather", default="auto", choices=["auto", "messages"],
+                    help="sweep form: auto = marginal-gather when exact, messages = always gather messages")
     args = ap.parse_args()
 
     import torch
@@ -109,6 +111,8 @@ def main():
         bp = S.bp_conditional(device=local_rank)
         bp.init_messages_device(bm, synth.true_conf(N, Q), 1234)
         bp.expand_bp_params(S.bp_blockmodel_state(synth.cab_matrix(Q, cin, cout), np.array(synth.group_sizes(N, Q), dtype=np.uint32)))
+        if args.gather == "messages":
+            bp.set_gather_mode(1)
         E2_total = g.E2
         runner = bp
     else:
@@ -123,12 +127,12 @@ def main():
         torch.cuda.synchronize()
 
     runner.set_timing(False)
-    runner.sweep(args.warmup, 1.0)
+    runner.sweep(args.warmup, 1.0, want_diff=False)
     runner.reset_stats()
     runner.set_timing(True)
     barrier()
     t1 = time.perf_counter()
-    runner.sweep(args.steps, 1.0)
+    runner.sweep(args.steps, 1.0, want_diff=False)
     barrier()
     dt = time.perf_counter() - t1
     if world > 1:
@@ -156,7 +160,7 @@ def main():
                 "setup_s": round(setup_s, 2)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_sweep<%d>" % Q, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "kernel": ("k_sweep_psi<%d>" if st.psi_form_sweeps else "k_sweep<%d>") % Q, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if sweeps_to_converge is not None:
             out["sweeps_to_converge"] = sweeps_to_converge

@@ -108,6 +108,13 @@ int sbmbp_get_field(sbmbp_engine_t *e, double *h /* Q */); /* h_ of belief_propa
  * convergence flag (the returned niter is exact regardless). */
 int sbmbp_set_schedule(sbmbp_engine_t *e, double field_mix, uint32_t check_every);
 
+/* Which form of the sweep kernel runs. 0 = automatic: incoming messages are reconstructed from the
+ * neighbours' marginals (same iterates, cache-friendly gather) whenever that is exact — damping 1,
+ * every cab entry > 0, no clamped rows, deg_corr_flag != 2 — with the reference's 1-step message
+ * criterion verified on the message buffers before convergence is declared; otherwise, and always
+ * with mode 1, incoming messages are gathered from the message array. */
+int sbmbp_set_gather_mode(sbmbp_engine_t *e, int mode);
+
 /* converge (belief_propagation.cpp:386-415): returns in *niter the 0-based index of the first sweep
  * whose max |delta message| < crit, or -1 after max_sweeps. damping == dumping_rate. */
 int sbmbp_converge(sbmbp_engine_t *e, double crit, uint32_t max_sweeps, double damping, int *niter,
@@ -163,6 +170,7 @@ typedef struct sbmbp_stats {
     uint64_t device_bytes;       /* HBM held by this engine */
     uint32_t n_blocks;           /* workgroups of one sweep launch */
     uint32_t n_hub_rows;         /* rows handled by the workgroup-per-row kernel */
+    uint64_t psi_form_sweeps;    /* of `sweeps`, how many ran the marginal-gather form */
 } sbmbp_stats;
 int sbmbp_get_stats(sbmbp_engine_t *e, sbmbp_stats *out);
 int sbmbp_reset_stats(sbmbp_engine_t *e);

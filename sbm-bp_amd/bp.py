@@ -200,6 +200,10 @@ class BeliefPropagation:
     def set_schedule(self, field_mix=1.0, check_every=1):
         check(self._lib.sbmbp_set_schedule(self._h, field_mix, check_every))
 
+    def set_gather_mode(self, mode=0):
+        """0 = automatic (marginal-gather sweep when exact), 1 = always gather messages"""
+        check(self._lib.sbmbp_set_gather_mode(self._h, mode))
+
     def set_nonedge_mode(self, mode=0, series_order=0):
         check(self._lib.sbmbp_set_nonedge_mode(self._h, mode, series_order))
 
@@ -210,7 +214,12 @@ class BeliefPropagation:
         check(self._lib.sbmbp_converge(self._h, conv_crit, time_conv, dumping_rate, C.byref(niter), C.byref(last)))
         return niter.value, last.value
 
-    def sweep(self, n_sweeps=1, dumping_rate=1.0):
+    def sweep(self, n_sweeps=1, dumping_rate=1.0, want_diff=True):
+        """exactly n_sweeps synchronous sweeps; returns the last max|delta message| (an extra streaming
+        pass over both message buffers in the marginal-gather form) unless want_diff is False"""
+        if not want_diff:
+            check(self._lib.sbmbp_sweep(self._h, dumping_rate, n_sweeps, None))
+            return None
         last = C.c_double(0.0)
         check(self._lib.sbmbp_sweep(self._h, dumping_rate, n_sweeps, C.byref(last)))
         return last.value

@@ -11,7 +11,19 @@ ARCH = "gfx950"
 
 
 def lib_path():
-    return os.path.join(CSRC, "libsbmbp_hip.so")
+    # SBMBP_LIB selects an alternative build of the same library (kernel tuning A/B runs)
+    return os.environ.get("SBMBP_LIB") or os.path.join(CSRC, "libsbmbp_hip.so")
+
+
+def build_variant(name, defines):
+    """compile a tuning variant csrc/variants/libsbmbp_<name>.so with extra -D flags"""
+    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "host_graph.cpp")]
+    vdir = os.path.join(CSRC, "variants")
+    os.makedirs(vdir, exist_ok=True)
+    out = os.path.join(vdir, "libsbmbp_%s.so" % name)
+    subprocess.check_call([_hipcc(), "-std=c++14", "-O3", "--offload-arch=" + ARCH, "-fPIC", "-shared", "-o", out] +
+                          ["-D" + d for d in defines] + srcs)
+    return out
 
 
 def bin_path():
@@ -32,7 +44,7 @@ def _hipcc():
 def build_lib(force=False, verbose=False):
     srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "host_graph.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("kernels.h", "host_graph.h")] + [os.path.join(ROOT, "include", "sbmbp.h")]
-    out = lib_path()
+    out = os.path.join(CSRC, "libsbmbp_hip.so")
     if force or _newer(out, deps):
         cmd = [_hipcc(), "-std=c++14", "-O3", "--offload-arch=" + ARCH, "-fPIC", "-shared", "-o", out] + srcs
         if verbose:

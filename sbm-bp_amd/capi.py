@@ -30,7 +30,7 @@ class LearnResult(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("sweeps", C.c_uint64), ("edge_msg_updates", C.c_uint64), ("sweep_kernel_ms", C.c_double),
                 ("sweep_launches", C.c_uint64), ("bytes_per_sweep", C.c_double), ("device_bytes", C.c_uint64),
-                ("n_blocks", C.c_uint32), ("n_hub_rows", C.c_uint32)]
+                ("n_blocks", C.c_uint32), ("n_hub_rows", C.c_uint32), ("psi_form_sweeps", C.c_uint64)]
 
 
 # every symbol include/sbmbp.h declares: name -> (restype, argtypes)
@@ -59,6 +59,7 @@ SYMBOLS = {
     "sbmbp_get_state": (C.c_int, [C.c_void_p, c_dp, c_dp]),
     "sbmbp_get_field": (C.c_int, [C.c_void_p, c_dp]),
     "sbmbp_set_schedule": (C.c_int, [C.c_void_p, C.c_double, C.c_uint32]),
+    "sbmbp_set_gather_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "sbmbp_converge": (C.c_int, [C.c_void_p, C.c_double, C.c_uint32, C.c_double, C.POINTER(C.c_int), c_dp]),
     "sbmbp_sweep": (C.c_int, [C.c_void_p, C.c_double, C.c_uint32, c_dp]),
     "sbmbp_free_energy": (C.c_int, [C.c_void_p, c_dp, c_dp]),

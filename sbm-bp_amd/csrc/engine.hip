@@ -47,10 +47,12 @@ struct sbmbp_engine {
     // state in HBM
     double *d_M[2] = {nullptr, nullptr};
     int cur = 0;
-    double *d_psi = nullptr;
+    double *d_psi[2] = {nullptr, nullptr};  // marginals, double buffered (the marginal-gather sweep reads one, writes the other)
+    int pcur = 0;
     dev_params *d_P = nullptr;
     double *d_partials = nullptr;
     size_t partials_cap = 0;  // doubles
+    double *d_stage = nullptr;  // first-stage fold output: FOLD_BLOCKS rows
     double *d_small = nullptr;  // folded results
     size_t small_cap = 0;
     double *d_hist = nullptr;
@@ -66,6 +68,10 @@ struct sbmbp_engine {
     double beta = 1.0;
     double sum_log_didl = 0.0;  // sum over directed edges of log(d_i d_l) (dc 1 constant of f_site/f_edge)
     bool have_params = false, have_state = false, has_clamp = false, field_fresh = false;
+    bool w_positive = false;     // every cab entry > 0: the marginal-gather sweep is well defined
+    bool psi_consistent = false; // psi == marginals of the message pair held in d_M (set by an undamped sweep)
+    int gather_mode = 0;         // 0 = automatic, 1 = always gather messages (explicit form)
+    uint64_t psi_sweeps = 0;     // sweeps executed by k_sweep_psi
     double field_mix = 1.0;
     uint32_t check_every = 1;
     int nonedge_mode = 0, series_order = 0;
@@ -107,8 +113,22 @@ int ensure_small(sbmbp_engine *e, size_t doubles) {
     return SBMBP_OK;
 }
 
-inline int frame_cap(uint32_t Q) { return BLOCK * (Q <= 2 ? 4 : 2); }
-inline int frame_rcap(uint32_t Q) { return Q <= 4 ? 2 * BLOCK : BLOCK; }
+constexpr uint32_t FOLD_BLOCKS = 256, FOLD_STRIDE_MAX = 64;
+
+// two-stage fold: when there are many partial rows, reduce them to FOLD_BLOCKS rows first.
+// Returns the pointer/row count the final single-workgroup stage should read.
+const double *fold_stage(sbmbp_engine *e, uint32_t *rows, int ncols_sum, int has_max, uint32_t stride) {
+    if (*rows <= 4 * FOLD_BLOCKS || stride > FOLD_STRIDE_MAX) return e->d_partials;
+    const uint32_t chunk = (*rows + FOLD_BLOCKS - 1) / FOLD_BLOCKS;
+    const uint32_t nb = (*rows + chunk - 1) / chunk;
+    hipLaunchKernelGGL(k_fold_stage, dim3(nb), dim3(BLOCK), 0, e->stream, e->d_partials, *rows, chunk, ncols_sum, has_max,
+                       stride, e->d_stage);
+    *rows = nb;
+    return e->d_stage;
+}
+
+inline int frame_cap(uint32_t Q) { return FTPB * (Q <= 2 ? SBMBP_EPT_LO : (Q <= 4 ? SBMBP_EPT_MID : SBMBP_EPT_HI)); }
+inline int frame_rcap(uint32_t Q) { const int cap = frame_cap(Q); return cap / 2 > 64 ? cap / 2 : 64; }
 
 // Q/dc dispatch over the templated kernels
 #define DISPATCH_Q(Qv, ...)                                             \
@@ -154,7 +174,7 @@ int launch_field(sbmbp_engine *e, int mode) {
     const uint32_t rows_per_blk = 4096;
     const uint32_t nb = std::max<uint32_t>(1, (e->N + rows_per_blk - 1) / rows_per_blk);
     CHK(ensure_partials(e, size_t(nb) * (e->Q + 1)));
-    DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_psi_sum<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_psi,
+    DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_psi_sum<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_psi[e->pcur],
                                         e->N, rows_per_blk, int(e->dc != 0), e->d_partials));
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, e->stream, e->d_partials, nb, int(e->Q), mode, e->d_P,
                        (double *)nullptr, 0u);
@@ -162,9 +182,15 @@ int launch_field(sbmbp_engine *e, int mode) {
     return SBMBP_OK;
 }
 
-int launch_sweep(sbmbp_engine *e, int src_buf, double damp) {
-    const double *Mold = e->d_M[src_buf];
-    double *Mnew = e->d_M[src_buf ^ 1];
+// One synchronous sweep, sweep number `j` of the current run_sweeps call (buffers alternate per
+// sweep). psi_form: reconstruct incoming messages from the neighbours' marginals (k_sweep_psi)
+// instead of gathering them from the message array (k_sweep).
+int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form) {
+    const int mc = (e->cur + int(j)) & 1, pc = (e->pcur + int(j)) & 1;
+    const double *Mold = e->d_M[mc];
+    double *Mnew = e->d_M[mc ^ 1];
+    const double *psi_old = e->d_psi[pc];
+    double *psi_new = e->d_psi[pc ^ 1];
     const int32_t *clamp = e->has_clamp ? e->d_clamp : nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (e->timing) {
@@ -177,28 +203,33 @@ int launch_sweep(sbmbp_engine *e, int src_buf, double damp) {
         e1 = e->ev[e->ev_used++];
         HIPCHK(hipEventRecord(e0, e->stream));
     }
-    if (e->dc == 2) {
-        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, true>), dim3(e->n_blk), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
-                                            e->d_rev, e->d_nbr, Mold, Mnew, e->d_psi, clamp, e->d_blk_row, e->d_P,
+    if (psi_form) {
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
+                                            Mnew, psi_old, psi_new, e->d_blk_row, e->d_P, int(e->dc), e->d_partials));
+    } else if (e->dc == 2) {
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, true>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
+                                            e->d_rev, e->d_nbr, Mold, Mnew, psi_old, psi_new, clamp, e->d_blk_row, e->d_P,
                                             1, damp, e->d_partials));
     } else {
-        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, false>), dim3(e->n_blk), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
-                                            e->d_rev, e->d_nbr, Mold, Mnew, e->d_psi, clamp, e->d_blk_row, e->d_P,
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, false>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
+                                            e->d_rev, e->d_nbr, Mold, Mnew, psi_old, psi_new, clamp, e->d_blk_row, e->d_P,
                                             int(e->dc), damp, e->d_partials));
     }
     if (e->timing) HIPCHK(hipEventRecord(e1, e->stream));
-    if (e->n_hub) {
+    if (e->n_hub) {  // hub rows always use the explicit form; it writes the same destination buffers
         if (e->dc == 2) {
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream,
-                                                e->d_row_ptr, e->d_rev, e->d_nbr, Mold, Mnew, e->d_psi, clamp,
+                                                e->d_row_ptr, e->d_rev, e->d_nbr, Mold, Mnew, psi_old, psi_new, clamp,
                                                 e->d_hub_row, e->d_hub_blk, e->d_P, 1, damp, e->d_partials));
         } else {
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, false>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream,
-                                                e->d_row_ptr, e->d_rev, e->d_nbr, Mold, Mnew, e->d_psi, clamp,
+                                                e->d_row_ptr, e->d_rev, e->d_nbr, Mold, Mnew, psi_old, psi_new, clamp,
                                                 e->d_hub_row, e->d_hub_blk, e->d_P, int(e->dc), damp, e->d_partials));
         }
     }
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, e->stream, e->d_partials, e->n_blk, int(e->Q), 0, e->d_P,
+    uint32_t rows = e->n_blk;
+    const double *part = fold_stage(e, &rows, int(e->Q), 1, e->Q + 1);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, e->stream, part, rows, int(e->Q), 0, e->d_P,
                        e->d_hist, e->hist_cap);
     HIPCHK(hipGetLastError());
     return SBMBP_OK;
@@ -224,37 +255,111 @@ int read_conv_state(sbmbp_engine *e, conv_state *cs) {
     return SBMBP_OK;
 }
 
+// exact criterion of the reference's converge(): max |m^{t+1} - m^t| over the two message buffers
+int message_diff(sbmbp_engine *e, double *out) {
+    const uint64_t n = e->E2 * e->Q;
+    if (n == 0) { *out = 0.0; return SBMBP_OK; }
+    const uint32_t nb = uint32_t(std::min<uint64_t>(2048, (n / 2 + BLOCK - 1) / BLOCK + 1));
+    CHK(ensure_partials(e, size_t(nb) * 2));
+    hipLaunchKernelGGL(k_msg_diff, dim3(nb), dim3(BLOCK), 0, e->stream, e->d_M[0], e->d_M[1], n, e->d_partials);
+    hipLaunchKernelGGL(k_fold_stage, dim3(1), dim3(BLOCK), 0, e->stream, e->d_partials, nb, nb, 1, 1, 2u, e->d_stage);
+    HIPCHK(hipGetLastError());
+    double r[2];
+    HIPCHK(hipMemcpyAsync(r, e->d_stage, 16, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *out = r[1];
+    return SBMBP_OK;
+}
+
+bool psi_form_allowed(const sbmbp_engine *e, double damping) {
+    return e->gather_mode == 0 && damping == 1.0 && !e->has_clamp && e->dc != 2 && e->w_positive && e->E2 > 0;
+}
+
+// The in-kernel hint of k_sweep_psi is the 2-step message difference.
+// With linear convergence at rate r the 2-step difference is (1 + 1/r) times the 1-step one, so the
+// device-side stop flag is armed early, at HINT_SCALE * crit, and from there the exact 1-step value
+// (k_msg_diff) is evaluated after every sweep and decides: never a false convergence, and the
+// returned niter equals the explicit form's unless r < 1/(HINT_SCALE - 1).
+constexpr double HINT_SCALE = 8.0;
+
 // run sweeps until convergence (crit >= 0) or exactly max_sweeps (crit < 0: never converges)
 int run_sweeps(sbmbp_engine *e, double crit, uint32_t max_sweeps, double damping, int *niter, double *last) {
     if (!e->have_params || !e->have_state) { set_error("set_params and init_messages/set_state must precede converge"); return SBMBP_ERR_STATE; }
+    const bool psi_ok = psi_form_allowed(e, damping);
     CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (e->Q + 1)));
-    CHK(upload_params(e, crit));
+    CHK(upload_params(e, (psi_ok && crit > 0) ? HINT_SCALE * crit : crit));
     CHK(launch_field(e, 1));
     CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (e->Q + 1)));
     uint32_t done = 0;
     conv_state cs{0.0, -1, 0, 0, 0};
     const uint32_t batch_max = std::max<uint32_t>(1, e->check_every);
+    const bool first_explicit = !e->psi_consistent;
+    uint64_t n_psi = 0;
+    int result_iter = -1;
+    double exact = -1.0;
     while (done < max_sweeps) {
         const uint32_t batch = std::min(batch_max, max_sweeps - done);
-        for (uint32_t b = 0; b < batch; ++b) CHK(launch_sweep(e, (e->cur + int(done + b)) & 1, damping));
+        for (uint32_t b = 0; b < batch; ++b) {
+            const uint32_t j = done + b;
+            const bool pf = psi_ok && !(j == 0 && first_explicit);
+            CHK(launch_sweep(e, j, damping, pf));
+        }
         CHK(read_conv_state(e, &cs));
         if (e->timing) CHK(collect_timing(e));
         done += batch;
         if (cs.stop) break;
     }
-    const uint32_t executed = uint32_t(cs.sweep_idx);
-    e->cur = (e->cur + int(executed)) & 1;
+    uint32_t executed = uint32_t(cs.sweep_idx);
+    auto commit = [&](uint32_t n) {
+        e->cur = (e->cur + int(n)) & 1;
+        e->pcur = (e->pcur + int(n)) & 1;
+    };
+    if (!psi_ok) {
+        commit(executed);
+        result_iter = cs.conv_iter;
+        exact = cs.maxdiff;
+    } else {
+        n_psi = executed - ((first_explicit && executed > 0) ? 1 : 0);
+        commit(executed);
+        if (executed > 0 && (last != nullptr || (cs.stop && crit > 0))) CHK(message_diff(e, &exact));
+        if (cs.stop && crit > 0) {
+            if (exact < crit) {
+                result_iter = cs.conv_iter;
+            } else {  // the hint fired early: continue one sweep at a time on the exact criterion
+                conv_state reset{0.0, -1, cs.sweep_idx, 0, 1};
+                while (executed < max_sweeps) {
+                    HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(e->d_P) + offsetof(dev_params, maxdiff), &reset,
+                                          sizeof reset, hipMemcpyHostToDevice, e->stream));
+                    const double never = -1.0;
+                    HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(e->d_P) + offsetof(dev_params, crit), &never, 8,
+                                          hipMemcpyHostToDevice, e->stream));
+                    CHK(launch_sweep(e, 0, damping, true));
+                    CHK(read_conv_state(e, &cs));
+                    if (e->timing) CHK(collect_timing(e));
+                    commit(1);
+                    ++executed;
+                    ++n_psi;
+                    reset.sweep_idx = cs.sweep_idx;
+                    CHK(message_diff(e, &exact));
+                    if (exact < crit) { result_iter = int(executed) - 1; break; }
+                }
+            }
+        }
+    }
     e->sweeps += executed;
-    e->field_fresh = (e->field_mix >= 1.0);
-    if (niter) *niter = cs.conv_iter;
-    if (last) *last = cs.maxdiff;
+    e->psi_sweeps += n_psi;
+    if (executed > 0) e->psi_consistent = (damping == 1.0 && !e->has_clamp && e->w_positive);
+    e->field_fresh = (e->field_mix >= 1.0) && executed > 0;
+    if (niter) *niter = result_iter;
+    if (last) *last = exact;
     return SBMBP_OK;
 }
 
 // fold [rows][stride] partials into d_small[0..cols) and copy to host
 int fold_to_host(sbmbp_engine *e, uint32_t rows, uint32_t cols, uint32_t stride, double *out) {
     CHK(ensure_small(e, cols));
-    hipLaunchKernelGGL(k_fold_rows_sum, dim3(1), dim3(BLOCK), 0, e->stream, e->d_partials, rows, cols, stride, e->d_small);
+    const double *part = fold_stage(e, &rows, int(cols), 0, stride);
+    hipLaunchKernelGGL(k_fold_rows_sum, dim3(1), dim3(BLOCK), 0, e->stream, part, rows, cols, stride, e->d_small);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, e->d_small, size_t(cols) * 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -272,14 +377,14 @@ int site_edge_terms(sbmbp_engine *e, bool want_entropy, double out[4]) {
     CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (FE_NP + 1)));
     const double *M = e->d_M[e->cur];
     if (e->dc == 2) {
-        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_frame<QQ, true>), dim3(e->n_blk), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_frame<QQ, true>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
                                             e->d_rev, e->d_nbr, M, e->d_blk_row, e->d_P, 1, int(want_entropy), e->d_partials));
         if (e->n_hub)
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
                                                 e->d_rev, e->d_nbr, M, e->d_hub_row, e->d_hub_blk, e->d_P, 1,
                                                 int(want_entropy), e->d_partials));
     } else {
-        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_frame<QQ, false>), dim3(e->n_blk), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_frame<QQ, false>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
                                             e->d_rev, e->d_nbr, M, e->d_blk_row, e->d_P, int(e->dc), int(want_entropy),
                                             e->d_partials));
         if (e->n_hub)
@@ -343,13 +448,13 @@ int nonedge_terms(sbmbp_engine *e, bool want_entropy, double out[2]) {
     if (exact) {
         const uint32_t g = (N + BLOCK - 1) / BLOCK;
         CHK(ensure_partials(e, size_t(g) * g * (NE_NP + 1)));
-        DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_exact<QQ>), dim3(g, g), dim3(BLOCK), 0, e->stream, e->d_psi, N, d_Pm,
+        DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_exact<QQ>), dim3(g, g), dim3(BLOCK), 0, e->stream, e->d_psi[e->pcur], N, d_Pm,
                                          d_cab, invN, int(want_entropy), e->d_partials));
         HIPCHK(hipGetLastError());
         CHK(fold_to_host(e, g * g, NE_NP, NE_NP + 1, all));
         CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (NE_NP + 1)));
-        DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_exact_adj<QQ>), dim3(e->n_blk), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
-                                         e->d_nbr, e->d_psi, d_Pm, d_cab, e->d_blk_row, invN, int(want_entropy),
+        DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_exact_adj<QQ>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
+                                         e->d_nbr, e->d_psi[e->pcur], d_Pm, d_cab, e->d_blk_row, invN, int(want_entropy),
                                          e->d_partials));
         HIPCHK(hipGetLastError());
         CHK(fold_to_host(e, e->n_blk, NE_NP, NE_NP + 1, adj));
@@ -363,7 +468,7 @@ int nonedge_terms(sbmbp_engine *e, bool want_entropy, double out[2]) {
         const uint32_t nb = std::max<uint32_t>(1, (N + rows_per_blk - 1) / rows_per_blk);
         CHK(ensure_partials(e, size_t(nb) * T));
         CHK(ensure_small(e, size_t(T)));
-        hipLaunchKernelGGL(k_moments, dim3(nb), dim3(BLOCK), 0, e->stream, e->d_psi, N, int(Q), K, rows_per_blk, T, e->d_partials);
+        hipLaunchKernelGGL(k_moments, dim3(nb), dim3(BLOCK), 0, e->stream, e->d_psi[e->pcur], N, int(Q), K, rows_per_blk, T, e->d_partials);
         hipLaunchKernelGGL(k_fold_columns, dim3((T + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_partials, nb,
                            uint32_t(T), e->d_small);
         HIPCHK(hipGetLastError());
@@ -387,8 +492,8 @@ int nonedge_terms(sbmbp_engine *e, bool want_entropy, double out[2]) {
             off += tsz;
         }
         CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (NE_NP + 1)));
-        DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_adj<QQ>), dim3(e->n_blk), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
-                                         e->d_nbr, e->d_psi, d_w, d_cab, e->d_blk_row, invN, int(want_entropy), e->d_partials));
+        DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_adj<QQ>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
+                                         e->d_nbr, e->d_psi[e->pcur], d_w, d_cab, e->d_blk_row, invN, int(want_entropy), e->d_partials));
         HIPCHK(hipGetLastError());
         CHK(fold_to_host(e, e->n_blk, NE_NP, NE_NP + 1, adj));
     }
@@ -404,7 +509,7 @@ int row_sums(sbmbp_engine *e, std::vector<double> &out /* 2Q + Q*Q */) {
     const uint32_t nb = std::max<uint32_t>(1, (e->N + rows_per_blk - 1) / rows_per_blk);
     CHK(ensure_partials(e, size_t(nb) * T));
     CHK(ensure_small(e, T));
-    DISPATCH_Q(Q, hipLaunchKernelGGL((k_row_sums<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_psi,
+    DISPATCH_Q(Q, hipLaunchKernelGGL((k_row_sums<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_psi[e->pcur],
                                      e->d_true, e->N, rows_per_blk, e->d_partials));
     hipLaunchKernelGGL(k_fold_columns, dim3((T + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_partials, nb, T, e->d_small);
     HIPCHK(hipGetLastError());
@@ -522,6 +627,10 @@ void apply_params_host(sbmbp_engine *e, const double *cab, const uint32_t *na, d
     e->beta = beta;
     e->have_params = true;
     e->field_fresh = false;
+    e->psi_consistent = false;  // the reconstruction psi / (W^T m) needs the W the marginals were formed with
+    e->w_positive = true;
+    for (uint32_t a = 0; a < Q * Q; ++a)
+        if (!(cab[a] > 0.0) || !(cab[a] < 1e300)) e->w_positive = false;
 }
 
 }  // namespace
@@ -653,13 +762,15 @@ int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint3
     TRY(dev_alloc(e, &e->d_clamp, e->N));
     TRY(dev_alloc(e, &e->d_M[0], e->E2 * Q));
     TRY(dev_alloc(e, &e->d_M[1], e->E2 * Q));
-    TRY(dev_alloc(e, &e->d_psi, size_t(e->N) * Q));
+    TRY(dev_alloc(e, &e->d_psi[0], size_t(e->N) * Q));
+    TRY(dev_alloc(e, &e->d_psi[1], size_t(e->N) * Q));
     TRY(dev_alloc(e, &e->d_P, 1));
     TRY(dev_alloc(e, &e->d_mats, 3 * Q * Q));
     e->hist_cap = 4096;
     TRY(dev_alloc(e, &e->d_hist, e->hist_cap));
     TRY(ensure_partials(e, size_t(e->n_blk) * (QMAX + 1)));
     TRY(ensure_small(e, 8192));
+    TRY(dev_alloc(e, &e->d_stage, size_t(FOLD_BLOCKS) * FOLD_STRIDE_MAX));
     TRYHIP(hipMemcpyAsync(e->d_row_ptr, rp32.data(), rp32.size() * 4, hipMemcpyHostToDevice, e->stream));
     if (e->E2) {
         TRYHIP(hipMemcpyAsync(e->d_rev, g->rev.data(), e->E2 * 4, hipMemcpyHostToDevice, e->stream));
@@ -694,7 +805,8 @@ void sbmbp_destroy(sbmbp_engine_t *e) {
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
     void *ptrs[] = {e->d_row_ptr, e->d_rev, e->d_nbr, e->d_src, e->d_blk_row, e->d_hub_row, e->d_hub_blk, e->d_true,
-                    e->d_clamp, e->d_M[0], e->d_M[1], e->d_psi, e->d_P, e->d_partials, e->d_small, e->d_hist, e->d_mats};
+                    e->d_clamp, e->d_M[0], e->d_M[1], e->d_psi[0], e->d_psi[1], e->d_P, e->d_partials, e->d_small, e->d_hist, e->d_mats,
+                    e->d_stage};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto ev : e->ev) hipEventDestroy(ev);
     if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
@@ -745,7 +857,7 @@ int sbmbp_init_messages(sbmbp_engine_t *e, uint32_t flag, const int32_t *conf, c
 int sbmbp_init_messages_device(sbmbp_engine_t *e, uint64_t seed, const uint32_t *true_conf) {
     if (!e) return SBMBP_ERR_ARG;
     CHK(upload_labels(e, nullptr, true_conf, 0, 0));
-    hipLaunchKernelGGL(k_init_random, dim3((e->N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_psi, uint64_t(e->N),
+    hipLaunchKernelGGL(k_init_random, dim3((e->N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_psi[e->pcur], uint64_t(e->N),
                        int(e->Q), seed, 0x1234567ull);
     if (e->E2)
         hipLaunchKernelGGL(k_init_random, dim3(uint32_t((e->E2 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, e->stream,
@@ -754,6 +866,7 @@ int sbmbp_init_messages_device(sbmbp_engine_t *e, uint64_t seed, const uint32_t 
     HIPCHK(hipStreamSynchronize(e->stream));
     e->have_state = true;
     e->field_fresh = false;
+    e->psi_consistent = false;
     return SBMBP_OK;
 }
 
@@ -771,16 +884,17 @@ int sbmbp_get_params(sbmbp_engine_t *e, double *cab, uint32_t *na) {
 
 int sbmbp_set_state(sbmbp_engine_t *e, const double *psi, const double *msg_out) {
     if (!e) return SBMBP_ERR_ARG;
-    if (psi) HIPCHK(hipMemcpyAsync(e->d_psi, psi, size_t(e->N) * e->Q * 8, hipMemcpyHostToDevice, e->stream));
+    if (psi) HIPCHK(hipMemcpyAsync(e->d_psi[e->pcur], psi, size_t(e->N) * e->Q * 8, hipMemcpyHostToDevice, e->stream));
     if (msg_out && e->E2) HIPCHK(hipMemcpyAsync(e->d_M[e->cur], msg_out, e->E2 * e->Q * 8, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (psi && msg_out) e->have_state = true;
     e->field_fresh = false;
+    e->psi_consistent = false;
     return SBMBP_OK;
 }
 int sbmbp_get_state(sbmbp_engine_t *e, double *psi, double *msg_out) {
     if (!e) return SBMBP_ERR_ARG;
-    if (psi) HIPCHK(hipMemcpyAsync(psi, e->d_psi, size_t(e->N) * e->Q * 8, hipMemcpyDeviceToHost, e->stream));
+    if (psi) HIPCHK(hipMemcpyAsync(psi, e->d_psi[e->pcur], size_t(e->N) * e->Q * 8, hipMemcpyDeviceToHost, e->stream));
     if (msg_out && e->E2) HIPCHK(hipMemcpyAsync(msg_out, e->d_M[e->cur], e->E2 * e->Q * 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return SBMBP_OK;
@@ -799,6 +913,12 @@ int sbmbp_set_schedule(sbmbp_engine_t *e, double field_mix, uint32_t check_every
     if (!e || !(field_mix > 0.0) || field_mix > 1.0 || check_every < 1) return SBMBP_ERR_ARG;
     e->field_mix = field_mix;
     e->check_every = check_every;
+    return SBMBP_OK;
+}
+
+int sbmbp_set_gather_mode(sbmbp_engine_t *e, int mode) {
+    if (!e || mode < 0 || mode > 1) return SBMBP_ERR_ARG;
+    e->gather_mode = mode;
     return SBMBP_OK;
 }
 
@@ -906,11 +1026,13 @@ int sbmbp_get_stats(sbmbp_engine_t *e, sbmbp_stats *out) {
     out->device_bytes = e->device_bytes;
     out->n_blocks = e->n_blk;
     out->n_hub_rows = e->n_hub;
+    out->psi_form_sweeps = e->psi_sweeps;
     return SBMBP_OK;
 }
 int sbmbp_reset_stats(sbmbp_engine_t *e) {
     if (!e) return SBMBP_ERR_ARG;
     e->sweeps = 0;
+    e->psi_sweeps = 0;
     e->sweep_ms = 0.0;
     e->sweep_launches = 0;
     return SBMBP_OK;

