@@ -78,7 +78,8 @@ int sbmbp_param_from_direct(uint32_t n_vertices, uint32_t Q, const double *pa, c
  * ------------------------------------------------------------------------------------------- */
 int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint32_t deg_corr_flag, int device);
 void sbmbp_destroy(sbmbp_engine_t *e);
-/* run all work of this engine on an existing HIP stream (hipStream_t passed as void*); NULL = own stream */
+/* run all work of this engine on an existing HIP stream (hipStream_t passed as void*; 0 = the default
+ * stream). Engines start on a private non-blocking stream. */
 int sbmbp_set_stream(sbmbp_engine_t *e, void *hip_stream);
 
 /* init_messages (belief_propagation.cpp:101-217): same std::mt19937(seed) stream and fill order as
@@ -176,6 +177,62 @@ int sbmbp_get_stats(sbmbp_engine_t *e, sbmbp_stats *out);
 int sbmbp_reset_stats(sbmbp_engine_t *e);
 /* when on, every sweep launch is bracketed by HIP events on the engine's stream (bench.py) */
 int sbmbp_set_timing(sbmbp_engine_t *e, int on);
+
+/* ---------------------------------------------------------------------------------------------
+ * Vertex-range sharding (one engine per GPU, one process per GPU). No reference counterpart: the
+ * reference is single-process. A shard owns a contiguous range of rows, their out-messages and
+ * marginals; the marginals of remote neighbours ("halo") live behind the owned rows in the same
+ * table, so nbr_local indexes one array. The caller (sbm-bp_amd/distributed.py) moves data
+ * between shards with torch.distributed (RCCL): halo marginals once per sweep (all-to-all) and
+ * the Q+1 reduction values (all-reduce); the shard entry points below are the steps in between.
+ * Sharded engines run the marginal-gather sweep only (damping 1, cab > 0, no clamped rows,
+ * deg_corr_flag 0/1) with the declared initial state taken as (psi^0, m^-1).
+ * All device buffers named here are caller-owned (torch tensors) so collectives can address them.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct sbmbp_shard_desc {
+    uint32_t n_global;          /* vertices of the whole graph (field scaling, eta) */
+    uint32_t n_own;             /* rows owned by this shard */
+    uint32_t n_halo;            /* remote vertices whose marginals this shard reads */
+    uint32_t row0;              /* global id of the first owned row */
+    uint64_t n_edges;           /* directed edges leaving the owned rows */
+    uint64_t edge0;             /* global index of the first owned directed edge (device RNG stream) */
+    const uint64_t *row_ptr;    /* host [n_own+1], local offsets */
+    const uint32_t *nbr_local;  /* host [n_edges]: index into the marginal table: own < n_own <= halo */
+    void *psi_buf0, *psi_buf1;  /* device, (n_own+n_halo)*Q doubles each */
+    void *red_buf;              /* device, >= 128 doubles: reduction hand-off buffer */
+} sbmbp_shard_desc;
+
+typedef struct sbmbp_conv_state {
+    double maxdiff; /* hint of the last executed sweep (2-step message difference) */
+    int conv_iter;  /* first sweep whose hint fell below the armed threshold, or -1 */
+    int sweep_idx;  /* sweeps executed since sbmbp_shard_begin */
+    int stop;       /* queued sweeps after the trigger were skipped */
+    int reserved;
+} sbmbp_conv_state;
+
+int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *desc, uint32_t Q, uint32_t deg_corr_flag, int device);
+/* start a run of sweeps: uploads parameters, arms the device-side stop flag at `armed_crit` (< 0: never) */
+int sbmbp_shard_begin(sbmbp_engine_t *e, double armed_crit);
+/* gather rows idx[0..n) of the marginal table that sweep j READS into out (device pointers) */
+int sbmbp_shard_pack(sbmbp_engine_t *e, uint32_t j, const uint32_t *d_idx, uint32_t n, double *d_out);
+/* which of the two marginal buffers sweep j reads (0/1); the other one is written */
+int sbmbp_shard_read_buffer(sbmbp_engine_t *e, uint32_t j);
+/* red[0..Q) = sum over owned rows of g_i psi_i of the buffer sweep j reads (field initialisation) */
+int sbmbp_shard_field_partial(sbmbp_engine_t *e, uint32_t j);
+/* sweep j over the owned rows; red[0..Q) = partial sums of the new marginals, red[Q] = hint */
+int sbmbp_shard_sweep_partial(sbmbp_engine_t *e, uint32_t j);
+/* consume red (already all-reduced by the caller): mode 0 after a sweep, 1 field initialisation */
+int sbmbp_shard_finalize(sbmbp_engine_t *e, int mode);
+/* red[0] = max |m_a - m_b| over the two message buffers of this shard (exact 1-step criterion) */
+int sbmbp_shard_msgdiff_partial(sbmbp_engine_t *e);
+/* red[0..2Q+Q*Q) = na_expect, nna_expect, confusion sums over the owned rows (current marginals) */
+int sbmbp_shard_rowsums_partial(sbmbp_engine_t *e);
+/* wait for the stream and read the convergence state */
+int sbmbp_shard_poll(sbmbp_engine_t *e, sbmbp_conv_state *out);
+/* after a poll: `executed` sweeps of the queued batch really ran; flips the buffer parities */
+int sbmbp_shard_commit(sbmbp_engine_t *e, uint32_t executed);
+/* re-arm after a trigger whose exact check failed: clears stop, sets the threshold */
+int sbmbp_shard_rearm(sbmbp_engine_t *e, double armed_crit);
 
 #ifdef __cplusplus
 }

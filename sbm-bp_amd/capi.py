@@ -73,6 +73,19 @@ SYMBOLS = {
     "sbmbp_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "sbmbp_reset_stats": (C.c_int, [C.c_void_p]),
     "sbmbp_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    # shard steps (sbm-bp_amd/distributed.py); desc/state structs are declared there
+    "sbmbp_shard_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]),
+    "sbmbp_shard_begin": (C.c_int, [C.c_void_p, C.c_double]),
+    "sbmbp_shard_pack": (C.c_int, [C.c_void_p, C.c_uint32, c_u32p, C.c_uint32, c_dp]),
+    "sbmbp_shard_read_buffer": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "sbmbp_shard_field_partial": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "sbmbp_shard_sweep_partial": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "sbmbp_shard_finalize": (C.c_int, [C.c_void_p, C.c_int]),
+    "sbmbp_shard_msgdiff_partial": (C.c_int, [C.c_void_p]),
+    "sbmbp_shard_rowsums_partial": (C.c_int, [C.c_void_p]),
+    "sbmbp_shard_poll": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sbmbp_shard_commit": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "sbmbp_shard_rearm": (C.c_int, [C.c_void_p, C.c_double]),
 }
 
 _LIB = None
@@ -83,6 +96,13 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # In a process that also uses PyTorch, torch's bundled HIP runtime must be loaded FIRST: our library
+    # then binds to that same runtime by soname (libamdhip64.so.7) and device pointers are shared.
+    # Loaded in the other order the process would hold two HIP runtimes and torch would see no GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = lib_path()
     if not os.path.exists(path):
         raise SbmbpError(-3, "native library missing", path + " (run __graft_entry__.build(); there is no CPU fallback)")

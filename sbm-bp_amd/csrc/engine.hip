@@ -37,8 +37,13 @@ struct sbmbp_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    uint32_t N = 0, Q = 0, dc = 0;
+    uint32_t N = 0, Q = 0, dc = 0;  // N = rows this engine updates (all vertices, or the owned range of a shard)
     uint64_t E2 = 0;
+    // sharding (sbmbp_shard_create): marginal table = owned rows followed by halo vertices
+    bool sharded = false, ext_psi = false;
+    uint32_t Nglob = 0, n_halo = 0, row0 = 0;
+    uint64_t edge0 = 0;
+    double *d_red = nullptr;  // caller-owned reduction hand-off buffer (shards)
     // graph + work decomposition in HBM
     uint32_t *d_row_ptr = nullptr, *d_rev = nullptr, *d_nbr = nullptr, *d_src = nullptr;
     uint32_t *d_blk_row = nullptr, *d_hub_row = nullptr, *d_hub_blk = nullptr, *d_true = nullptr;
@@ -149,14 +154,14 @@ int upload_params(sbmbp_engine *e, double crit) {
     const uint32_t Q = e->Q;
     for (uint32_t a = 0; a < Q * Q; ++a) {
         P.cab[a] = e->cab[a];
-        P.W[a] = (e->dc == 0) ? std::pow(e->cab[a], e->beta) : (e->dc == 1 ? e->cab[a] : e->cab[a] / double(e->N));
+        P.W[a] = (e->dc == 0) ? std::pow(e->cab[a], e->beta) : (e->dc == 1 ? e->cab[a] : e->cab[a] / double(e->Nglob));
     }
     for (uint32_t q = 0; q < Q; ++q) {
         P.eta[q] = e->eta[q];
         P.logeta[q] = std::log(e->eta[q]);
     }
     P.beta = e->beta;
-    P.invN = 1.0 / double(e->N);
+    P.invN = 1.0 / double(e->Nglob);
     P.field_mix = e->field_mix;
     P.crit = crit;
     P.maxdiff = 0.0;
@@ -216,7 +221,11 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form) {
                                             int(e->dc), damp, e->d_partials));
     }
     if (e->timing) HIPCHK(hipEventRecord(e1, e->stream));
-    if (e->n_hub) {  // hub rows always use the explicit form; it writes the same destination buffers
+    if (e->n_hub && psi_form) {
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi_hub<QQ>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
+                                            e->d_nbr, Mnew, psi_old, psi_new, e->d_hub_row, e->d_hub_blk, e->d_P,
+                                            int(e->dc), e->d_partials));
+    } else if (e->n_hub) {
         if (e->dc == 2) {
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream,
                                                 e->d_row_ptr, e->d_rev, e->d_nbr, Mold, Mnew, psi_old, psi_new, clamp,
@@ -623,7 +632,7 @@ void apply_params_host(sbmbp_engine *e, const double *cab, const uint32_t *na, d
     e->cab.assign(cab, cab + Q * Q);
     e->na.assign(na, na + Q);
     e->eta.resize(Q);
-    for (uint32_t q = 0; q < Q; ++q) e->eta[q] = 1.0 * e->na[q] / e->N;  // bp.cpp:307
+    for (uint32_t q = 0; q < Q; ++q) e->eta[q] = 1.0 * e->na[q] / e->Nglob;  // bp.cpp:307
     e->beta = beta;
     e->have_params = true;
     e->field_fresh = false;
@@ -636,6 +645,9 @@ void apply_params_host(sbmbp_engine *e, const double *cab, const uint32_t *na, d
 }  // namespace
 
 // =============================================== C ABI ==========================================
+#define NOT_SHARD(e) do { if ((e)->sharded) { set_error("not available on a sharded engine: use the shard steps (sbm-bp_amd/distributed.py)"); return SBMBP_ERR_UNSUPPORTED; } } while (0)
+#define IS_SHARD(e) do { if (!(e) || !(e)->sharded) { set_error("engine was not created with sbmbp_shard_create"); return SBMBP_ERR_ARG; } } while (0)
+
 extern "C" {
 
 const char *sbmbp_strerror(int code) {
@@ -718,6 +730,7 @@ int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint3
     auto *e = new sbmbp_engine();
     HIPCHK(hipGetDevice(&e->device));
     e->N = g->n;
+    e->Nglob = g->n;
     e->Q = Q;
     e->dc = dc;
     e->E2 = g->e2();
@@ -804,6 +817,7 @@ void sbmbp_destroy(sbmbp_engine_t *e) {
     if (!e) return;
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->ext_psi) e->d_psi[0] = e->d_psi[1] = nullptr;  // caller-owned
     void *ptrs[] = {e->d_row_ptr, e->d_rev, e->d_nbr, e->d_src, e->d_blk_row, e->d_hub_row, e->d_hub_blk, e->d_true,
                     e->d_clamp, e->d_M[0], e->d_M[1], e->d_psi[0], e->d_psi[1], e->d_P, e->d_partials, e->d_small, e->d_hist, e->d_mats,
                     e->d_stage};
@@ -817,8 +831,8 @@ int sbmbp_set_stream(sbmbp_engine_t *e, void *hip_stream) {
     if (!e) return SBMBP_ERR_ARG;
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->own_stream && e->stream) HIPCHK(hipStreamDestroy(e->stream));
-    if (hip_stream) { e->stream = static_cast<hipStream_t>(hip_stream); e->own_stream = false; }
-    else { HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)); e->own_stream = true; }
+    e->stream = static_cast<hipStream_t>(hip_stream);  // 0 is the (legacy) default stream, e.g. torch's current stream
+    e->own_stream = false;
     return SBMBP_OK;
 }
 
@@ -858,10 +872,12 @@ int sbmbp_init_messages_device(sbmbp_engine_t *e, uint64_t seed, const uint32_t 
     if (!e) return SBMBP_ERR_ARG;
     CHK(upload_labels(e, nullptr, true_conf, 0, 0));
     hipLaunchKernelGGL(k_init_random, dim3((e->N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_psi[e->pcur], uint64_t(e->N),
-                       int(e->Q), seed, 0x1234567ull);
+                       int(e->Q), seed, 0x1234567ull, uint64_t(e->row0));
     if (e->E2)
         hipLaunchKernelGGL(k_init_random, dim3(uint32_t((e->E2 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, e->stream,
-                           e->d_M[e->cur], e->E2, int(e->Q), seed, 0xabcdef01ull);
+                           e->d_M[e->cur], e->E2, int(e->Q), seed, 0xabcdef01ull, e->edge0);
+    if (e->E2 && e->sharded)
+        HIPCHK(hipMemcpyAsync(e->d_M[e->cur ^ 1], e->d_M[e->cur], e->E2 * e->Q * 8, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     e->have_state = true;
@@ -886,6 +902,8 @@ int sbmbp_set_state(sbmbp_engine_t *e, const double *psi, const double *msg_out)
     if (!e) return SBMBP_ERR_ARG;
     if (psi) HIPCHK(hipMemcpyAsync(e->d_psi[e->pcur], psi, size_t(e->N) * e->Q * 8, hipMemcpyHostToDevice, e->stream));
     if (msg_out && e->E2) HIPCHK(hipMemcpyAsync(e->d_M[e->cur], msg_out, e->E2 * e->Q * 8, hipMemcpyHostToDevice, e->stream));
+    // a sharded engine takes the declared state as (psi^0, m^-1): sweep 0 reads the buffer it then overwrites
+    if (msg_out && e->E2 && e->sharded) HIPCHK(hipMemcpyAsync(e->d_M[e->cur ^ 1], msg_out, e->E2 * e->Q * 8, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (psi && msg_out) e->have_state = true;
     e->field_fresh = false;
@@ -901,6 +919,7 @@ int sbmbp_get_state(sbmbp_engine_t *e, double *psi, double *msg_out) {
 }
 int sbmbp_get_field(sbmbp_engine_t *e, double *h) {
     if (!e || !h) return SBMBP_ERR_ARG;
+    NOT_SHARD(e);
     CHK(refresh_field(e));
     dev_params P;
     HIPCHK(hipMemcpyAsync(&P, e->d_P, sizeof P, hipMemcpyDeviceToHost, e->stream));
@@ -924,10 +943,12 @@ int sbmbp_set_gather_mode(sbmbp_engine_t *e, int mode) {
 
 int sbmbp_converge(sbmbp_engine_t *e, double crit, uint32_t max_sweeps, double damping, int *niter, double *last) {
     if (!e) return SBMBP_ERR_ARG;
+    NOT_SHARD(e);
     return run_sweeps(e, crit, max_sweeps, damping, niter, last);
 }
 int sbmbp_sweep(sbmbp_engine_t *e, double damping, uint32_t n_sweeps, double *last) {
     if (!e) return SBMBP_ERR_ARG;
+    NOT_SHARD(e);
     const uint32_t keep = e->check_every;
     e->check_every = std::max<uint32_t>(keep, 64);  // no convergence test: sync rarely
     int r = run_sweeps(e, -1.0, n_sweeps, damping, nullptr, last);
@@ -937,10 +958,12 @@ int sbmbp_sweep(sbmbp_engine_t *e, double damping, uint32_t n_sweeps, double *la
 
 int sbmbp_free_energy(sbmbp_engine_t *e, double *f, double *parts) {
     if (!e) return SBMBP_ERR_ARG;
+    NOT_SHARD(e);
     return free_energy_impl(e, f, parts);
 }
 int sbmbp_entropy(sbmbp_engine_t *e, double *ent, double *parts) {
     if (!e) return SBMBP_ERR_ARG;
+    NOT_SHARD(e);
     return entropy_impl(e, ent, parts);
 }
 int sbmbp_set_nonedge_mode(sbmbp_engine_t *e, int mode, int order) {
@@ -951,19 +974,23 @@ int sbmbp_set_nonedge_mode(sbmbp_engine_t *e, int mode, int order) {
 }
 int sbmbp_em_expectations(sbmbp_engine_t *e, double *na_e, double *nna_e, double *cab_e) {
     if (!e) return SBMBP_ERR_ARG;
+    NOT_SHARD(e);
     return em_expect(e, na_e, nna_e, cab_e);
 }
 int sbmbp_confusion(sbmbp_engine_t *e, double *C) {
     if (!e || !C) return SBMBP_ERR_ARG;
+    NOT_SHARD(e);
     return overlap_impl(e, nullptr, C);
 }
 int sbmbp_overlap(sbmbp_engine_t *e, double *ov) {
     if (!e || !ov) return SBMBP_ERR_ARG;
+    NOT_SHARD(e);
     return overlap_impl(e, ov, nullptr);
 }
 
 int sbmbp_inference(sbmbp_engine_t *e, float conv_crit, uint32_t time_conv, float dumping_rate, sbmbp_infer_result *out) {
     if (!e || !out) return SBMBP_ERR_ARG;
+    NOT_SHARD(e);
     // belief_propagation::inference (bp.cpp:77-99); crit and damping arrive as float, compared as double (:406)
     CHK(run_sweeps(e, double(conv_crit), time_conv, double(dumping_rate), &out->niter, &out->last_maxdiff));
     CHK(free_energy_impl(e, &out->free_energy, nullptr));
@@ -975,6 +1002,7 @@ int sbmbp_inference(sbmbp_engine_t *e, float conv_crit, uint32_t time_conv, floa
 int sbmbp_learning(sbmbp_engine_t *e, float learning_conv_crit, uint32_t learning_max_time, float learning_rate,
                    float dumping_rate, sbmbp_learn_result *out) {
     if (!e || !out) return SBMBP_ERR_ARG;
+    NOT_SHARD(e);
     if (!e->have_params || !e->have_state) { set_error("set_params and init_messages must precede learning"); return SBMBP_ERR_STATE; }
     const uint32_t Q = e->Q;
     std::vector<double> na_e(Q), nna_e(Q), cab_e(Q * Q);
@@ -1040,6 +1068,225 @@ int sbmbp_reset_stats(sbmbp_engine_t *e) {
 int sbmbp_set_timing(sbmbp_engine_t *e, int on) {
     if (!e) return SBMBP_ERR_ARG;
     e->timing = on != 0;
+    return SBMBP_OK;
+}
+
+// ------------------------------------------ shard steps ------------------------------------------
+
+int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *d, uint32_t Q, uint32_t dc, int device) {
+    if (!out || !d || !d->row_ptr || (!d->nbr_local && d->n_edges) || !d->psi_buf0 || !d->psi_buf1 || !d->red_buf) return SBMBP_ERR_ARG;
+    if (Q < 2 || Q > SBMBP_MAX_Q) { set_error("Q must be in [2, 8]"); return SBMBP_ERR_UNSUPPORTED; }
+    if (dc > 1) { set_error("sharded engines support deg_corr_flag 0 and 1"); return SBMBP_ERR_UNSUPPORTED; }
+    if (d->n_own == 0 || d->n_global == 0) { set_error("empty shard"); return SBMBP_ERR_ARG; }
+    if (d->row_ptr[0] != 0 || d->row_ptr[d->n_own] != d->n_edges || d->n_edges >= (uint64_t(1) << 32)) { set_error("shard row_ptr does not span [0, n_edges]"); return SBMBP_ERR_ARG; }
+    const uint64_t table_rows = uint64_t(d->n_own) + d->n_halo;
+    for (uint64_t k = 0; k < d->n_edges; ++k)
+        if (d->nbr_local[k] >= table_rows) { set_error("nbr_local entry outside the marginal table"); return SBMBP_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device visible; the engine has no CPU fallback"); return SBMBP_ERR_NODEVICE; }
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    auto *e = new sbmbp_engine();
+    HIPCHK(hipGetDevice(&e->device));
+    e->sharded = true;
+    e->ext_psi = true;
+    e->N = d->n_own;
+    e->Nglob = d->n_global;
+    e->n_halo = d->n_halo;
+    e->row0 = d->row0;
+    e->edge0 = d->edge0;
+    e->Q = Q;
+    e->dc = dc;
+    e->E2 = d->n_edges;
+    e->d_psi[0] = static_cast<double *>(d->psi_buf0);
+    e->d_psi[1] = static_cast<double *>(d->psi_buf1);
+    e->d_red = static_cast<double *>(d->red_buf);
+    HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->own_stream = true;
+    const uint32_t cap = uint32_t(frame_cap(Q)), rcap = uint32_t(frame_rcap(Q));
+    std::vector<uint32_t> blk_row, hub_row, hub_blk, rp32(size_t(d->n_own) + 1);
+    blk_row.push_back(0);
+    uint32_t rows = 0, edges = 0;
+    for (uint32_t i = 0; i < d->n_own; ++i) {
+        if (d->row_ptr[i + 1] < d->row_ptr[i]) { delete e; set_error("row_ptr not monotone"); return SBMBP_ERR_ARG; }
+        const uint32_t dg = uint32_t(d->row_ptr[i + 1] - d->row_ptr[i]);
+        if (dg > cap) {
+            if (rows) { blk_row.push_back(i); rows = 0; edges = 0; }
+            hub_row.push_back(i);
+            hub_blk.push_back(uint32_t(blk_row.size() - 1));
+            blk_row.push_back(i + 1);
+            continue;
+        }
+        if (rows + 1 > rcap || edges + dg > cap) { blk_row.push_back(i); rows = 0; edges = 0; }
+        rows++;
+        edges += dg;
+    }
+    if (blk_row.back() != d->n_own) blk_row.push_back(d->n_own);
+    for (size_t i = 0; i <= d->n_own; ++i) rp32[i] = uint32_t(d->row_ptr[i]);
+    e->h_row_ptr = rp32;
+    e->n_blk = uint32_t(blk_row.size() - 1);
+    e->n_hub = uint32_t(hub_row.size());
+    int r;
+#define TRY(x) if ((r = (x)) != SBMBP_OK) { sbmbp_destroy(e); return r; }
+#define TRYHIP(x) do { hipError_t _h = (x); if (_h != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(_h)); sbmbp_destroy(e); return SBMBP_ERR_HIP; } } while (0)
+    TRY(dev_alloc(e, &e->d_row_ptr, rp32.size()));
+    TRY(dev_alloc(e, &e->d_nbr, e->E2));
+    TRY(dev_alloc(e, &e->d_blk_row, blk_row.size()));
+    TRY(dev_alloc(e, &e->d_hub_row, hub_row.size()));
+    TRY(dev_alloc(e, &e->d_hub_blk, hub_blk.size()));
+    TRY(dev_alloc(e, &e->d_true, e->N));
+    TRY(dev_alloc(e, &e->d_M[0], e->E2 * Q));
+    TRY(dev_alloc(e, &e->d_M[1], e->E2 * Q));
+    TRY(dev_alloc(e, &e->d_P, 1));
+    e->hist_cap = 4096;
+    TRY(dev_alloc(e, &e->d_hist, e->hist_cap));
+    TRY(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 64)) * (QMAX + 1)));
+    TRY(ensure_small(e, 8192));
+    TRY(dev_alloc(e, &e->d_stage, size_t(FOLD_BLOCKS) * FOLD_STRIDE_MAX));
+    TRYHIP(hipMemcpyAsync(e->d_row_ptr, rp32.data(), rp32.size() * 4, hipMemcpyHostToDevice, e->stream));
+    if (e->E2) TRYHIP(hipMemcpyAsync(e->d_nbr, d->nbr_local, e->E2 * 4, hipMemcpyHostToDevice, e->stream));
+    TRYHIP(hipMemcpyAsync(e->d_blk_row, blk_row.data(), blk_row.size() * 4, hipMemcpyHostToDevice, e->stream));
+    if (e->n_hub) {
+        TRYHIP(hipMemcpyAsync(e->d_hub_row, hub_row.data(), hub_row.size() * 4, hipMemcpyHostToDevice, e->stream));
+        TRYHIP(hipMemcpyAsync(e->d_hub_blk, hub_blk.data(), hub_blk.size() * 4, hipMemcpyHostToDevice, e->stream));
+    }
+    TRYHIP(hipMemsetAsync(e->d_true, 0, size_t(e->N) * 4, e->stream));
+    TRYHIP(hipMemsetAsync(e->d_partials, 0, e->partials_cap * 8, e->stream));
+    TRYHIP(hipStreamSynchronize(e->stream));
+#undef TRY
+#undef TRYHIP
+    *out = e;
+    return SBMBP_OK;
+}
+
+int sbmbp_shard_begin(sbmbp_engine_t *e, double armed_crit) {
+    IS_SHARD(e);
+    if (!e->have_params || !e->have_state) { set_error("set_params and an initial state must precede shard sweeps"); return SBMBP_ERR_STATE; }
+    if (!e->w_positive) { set_error("sharded engines need every cab entry > 0"); return SBMBP_ERR_UNSUPPORTED; }
+    return upload_params(e, armed_crit);
+}
+
+int sbmbp_shard_read_buffer(sbmbp_engine_t *e, uint32_t j) { return (e && e->sharded) ? ((e->pcur + int(j)) & 1) : SBMBP_ERR_ARG; }
+
+int sbmbp_shard_pack(sbmbp_engine_t *e, uint32_t j, const uint32_t *d_idx, uint32_t n, double *d_out) {
+    IS_SHARD(e);
+    if (n == 0) return SBMBP_OK;
+    const double *table = e->d_psi[(e->pcur + int(j)) & 1];
+    const uint64_t tot = uint64_t(n) * e->Q;
+    hipLaunchKernelGGL(k_pack_rows, dim3(uint32_t((tot + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, e->stream, table, d_idx, n, int(e->Q), d_out);
+    HIPCHK(hipGetLastError());
+    return SBMBP_OK;
+}
+
+int sbmbp_shard_field_partial(sbmbp_engine_t *e, uint32_t j) {
+    IS_SHARD(e);
+    const uint32_t rows_per_blk = 4096;
+    const uint32_t nb = std::max<uint32_t>(1, (e->N + rows_per_blk - 1) / rows_per_blk);
+    CHK(ensure_partials(e, size_t(nb) * (e->Q + 1)));
+    DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_psi_sum<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
+                                        e->d_psi[(e->pcur + int(j)) & 1], e->N, rows_per_blk, int(e->dc != 0), e->d_partials));
+    hipLaunchKernelGGL(k_fold_stage, dim3(1), dim3(BLOCK), 0, e->stream, e->d_partials, nb, nb, int(e->Q), 1, e->Q + 1, e->d_red);
+    HIPCHK(hipGetLastError());
+    return SBMBP_OK;
+}
+
+int sbmbp_shard_sweep_partial(sbmbp_engine_t *e, uint32_t j) {
+    IS_SHARD(e);
+    const int mc = (e->cur + int(j)) & 1, pc = (e->pcur + int(j)) & 1;
+    double *Mio = e->d_M[mc ^ 1];
+    const double *psi_old = e->d_psi[pc];
+    double *psi_new = e->d_psi[pc ^ 1];
+    CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (e->Q + 1)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (e->timing) {
+        if (e->ev_used + 2 > e->ev.size()) {
+            size_t old = e->ev.size();
+            e->ev.resize(old + 256);
+            for (size_t i = old; i < e->ev.size(); ++i) HIPCHK(hipEventCreate(&e->ev[i]));
+        }
+        e0 = e->ev[e->ev_used++];
+        e1 = e->ev[e->ev_used++];
+        HIPCHK(hipEventRecord(e0, e->stream));
+    }
+    DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr, Mio,
+                                        psi_old, psi_new, e->d_blk_row, e->d_P, int(e->dc), e->d_partials));
+    if (e->timing) HIPCHK(hipEventRecord(e1, e->stream));
+    if (e->n_hub)
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi_hub<QQ>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
+                                            e->d_nbr, Mio, psi_old, psi_new, e->d_hub_row, e->d_hub_blk, e->d_P,
+                                            int(e->dc), e->d_partials));
+    uint32_t rows = e->n_blk;
+    const double *part = fold_stage(e, &rows, int(e->Q), 1, e->Q + 1);
+    hipLaunchKernelGGL(k_fold_stage, dim3(1), dim3(BLOCK), 0, e->stream, part, rows, rows, int(e->Q), 1, e->Q + 1, e->d_red);
+    HIPCHK(hipGetLastError());
+    return SBMBP_OK;
+}
+
+int sbmbp_shard_finalize(sbmbp_engine_t *e, int mode) {
+    IS_SHARD(e);
+    if (mode != 0 && mode != 1) return SBMBP_ERR_ARG;
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, e->stream, e->d_red, 1u, int(e->Q), mode, e->d_P, e->d_hist, e->hist_cap);
+    HIPCHK(hipGetLastError());
+    return SBMBP_OK;
+}
+
+int sbmbp_shard_msgdiff_partial(sbmbp_engine_t *e) {
+    IS_SHARD(e);
+    const uint64_t n = e->E2 * e->Q;
+    if (n == 0) { HIPCHK(hipMemsetAsync(e->d_red, 0, 8, e->stream)); return SBMBP_OK; }
+    const uint32_t nb = uint32_t(std::min<uint64_t>(2048, (n / 2 + BLOCK - 1) / BLOCK + 1));
+    CHK(ensure_partials(e, size_t(nb) * 2));
+    hipLaunchKernelGGL(k_msg_diff, dim3(nb), dim3(BLOCK), 0, e->stream, e->d_M[0], e->d_M[1], n, e->d_partials);
+    hipLaunchKernelGGL(k_fold_stage, dim3(1), dim3(BLOCK), 0, e->stream, e->d_partials, nb, nb, 1, 1, 2u, e->d_stage);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(e->d_red, e->d_stage + 1, 8, hipMemcpyDeviceToDevice, e->stream));
+    return SBMBP_OK;
+}
+
+int sbmbp_shard_rowsums_partial(sbmbp_engine_t *e) {
+    IS_SHARD(e);
+    const uint32_t Q = e->Q, T = 2 * Q + Q * Q;
+    const uint32_t rows_per_blk = 8192;
+    const uint32_t nb = std::max<uint32_t>(1, (e->N + rows_per_blk - 1) / rows_per_blk);
+    CHK(ensure_partials(e, size_t(nb) * T));
+    DISPATCH_Q(Q, hipLaunchKernelGGL((k_row_sums<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_psi[e->pcur],
+                                     e->d_true, e->N, rows_per_blk, e->d_partials));
+    hipLaunchKernelGGL(k_fold_columns, dim3((T + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_partials, nb, T, e->d_red);
+    HIPCHK(hipGetLastError());
+    return SBMBP_OK;
+}
+
+int sbmbp_shard_poll(sbmbp_engine_t *e, sbmbp_conv_state *out) {
+    IS_SHARD(e);
+    if (!out) return SBMBP_ERR_ARG;
+    conv_state cs;
+    CHK(read_conv_state(e, &cs));
+    if (e->timing) CHK(collect_timing(e));
+    out->maxdiff = cs.maxdiff;
+    out->conv_iter = cs.conv_iter;
+    out->sweep_idx = cs.sweep_idx;
+    out->stop = cs.stop;
+    out->reserved = 0;
+    return SBMBP_OK;
+}
+
+int sbmbp_shard_commit(sbmbp_engine_t *e, uint32_t executed) {
+    IS_SHARD(e);
+    e->cur = (e->cur + int(executed)) & 1;
+    e->pcur = (e->pcur + int(executed)) & 1;
+    e->sweeps += executed;
+    e->psi_sweeps += executed;
+    return SBMBP_OK;
+}
+
+int sbmbp_shard_rearm(sbmbp_engine_t *e, double armed_crit) {
+    IS_SHARD(e);
+    conv_state cs;
+    CHK(read_conv_state(e, &cs));
+    conv_state reset{0.0, -1, cs.sweep_idx, 0, 1};
+    HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(e->d_P) + offsetof(dev_params, maxdiff), &reset, sizeof reset,
+                          hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(e->d_P) + offsetof(dev_params, crit), &armed_crit, 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return SBMBP_OK;
 }
 

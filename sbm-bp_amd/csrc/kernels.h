@@ -504,6 +504,105 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     block_reduce_store<Q, FWAVES>(Sacc, md, sred, partials + size_t(blockIdx.x) * (Q + 1));
 }
 
+// K1ph: marginal-gather form of the hub-row update (one workgroup per row with degree > CAP)
+template <int Q>
+__global__ void __launch_bounds__(BLOCK)
+k_sweep_psi_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, double *__restrict__ Mio,
+                const double *__restrict__ psi_old, double *__restrict__ psi_new, const uint32_t *__restrict__ hub_row,
+                const uint32_t *__restrict__ hub_blk, const dev_params *__restrict__ P, int dc,
+                double *__restrict__ partials) {
+    if (P->stop) return;
+    __shared__ double sAq[BLOCK * Q];
+    __shared__ int sex[BLOCK];
+    __shared__ double sred[4 * (Q + 1)];
+    const int tid = threadIdx.x;
+    const uint32_t i = hub_row[blockIdx.x];
+    const uint32_t e0 = row_ptr[i], d = row_ptr[i + 1] - e0;
+    const double di = double(d);
+    double Sacc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) Sacc[q] = 0.0;
+    double md = 0.0;
+    double A[Q];
+    int ex = 0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) A[q] = 1.0;
+    auto incoming_field = [&](uint32_t le, double (&mo)[Q], double (&b)[Q]) {
+        double pl[Q], bo[Q], inc[Q];
+        load_vec<Q>(psi_old + size_t(nbr[e0 + le]) * Q, pl);
+        load_vec<Q>(Mio + size_t(e0 + le) * Q, mo);
+        edge_field<Q, false>(P, mo, 0.0, bo);
+        double tot = 0.0;
+#pragma unroll
+        for (int s = 0; s < Q; ++s) { inc[s] = pl[s] / bo[s]; tot += inc[s]; }
+        const double inv = 1.0 / tot;
+#pragma unroll
+        for (int s = 0; s < Q; ++s) inc[s] *= inv;
+        edge_field<Q, false>(P, inc, 0.0, b);
+    };
+    for (uint32_t le = tid; le < d; le += BLOCK) {
+        double mo[Q], b[Q];
+        incoming_field(le, mo, b);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) A[q] *= b[q];
+        ex += rescale_pow2<Q>(A);
+    }
+    store_vec<Q>(&sAq[tid * Q], A);
+    sex[tid] = ex;
+    __syncthreads();
+    for (int s = BLOCK / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            double o[Q];
+            load_vec<Q>(&sAq[(tid + s) * Q], o);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) A[q] *= o[q];
+            ex += sex[tid + s];
+            ex += rescale_pow2<Q>(A);
+            store_vec<Q>(&sAq[tid * Q], A);
+            sex[tid] = ex;
+        }
+        __syncthreads();
+    }
+    load_vec<Q>(&sAq[0], A);
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        A[q] *= dc ? P->eta[q] * exp(-di * P->hN[q]) : P->etaF[q];
+        tot += A[q];
+    }
+    const double inv = 1.0 / tot;
+    if (tid == 0) {
+        double pv[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { pv[q] = A[q] * inv; Sacc[q] = (dc ? di : 1.0) * pv[q]; }
+        store_vec<Q>(psi_new + size_t(i) * Q, pv);
+    }
+    for (uint32_t le = tid; le < d; le += BLOCK) {
+        double mo[Q], b[Q], out[Q], cav[Q];
+        incoming_field(le, mo, b);
+        double ct = 0.0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { cav[q] = A[q] / b[q]; ct += cav[q]; }
+        const double ci = 1.0 / ct;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            out[q] = cav[q] * ci;
+            md = nanmax(md, fabs(mo[q] - out[q]));
+        }
+        store_vec<Q>(Mio + size_t(e0 + le) * Q, out);
+    }
+    block_reduce_store<Q>(Sacc, md, sred, partials + size_t(hub_blk[blockIdx.x]) * (Q + 1));
+}
+
+// gather rows idx[0..n) of a [rows][Q] table into a contiguous buffer (halo send packing)
+__global__ void __launch_bounds__(BLOCK)
+k_pack_rows(const double *__restrict__ table, const uint32_t *__restrict__ idx, uint32_t n, int Q, double *__restrict__ out) {
+    const uint64_t t = uint64_t(blockIdx.x) * BLOCK + threadIdx.x;
+    if (t >= uint64_t(n) * Q) return;
+    const uint32_t r = uint32_t(t / Q), q = uint32_t(t % Q);
+    out[t] = table[size_t(idx[r]) * Q + q];
+}
+
 // exact 1-step criterion of converge (bp.cpp:1059-1063): max over all message entries |a - b|
 __global__ void __launch_bounds__(BLOCK)
 k_msg_diff(const double *__restrict__ a, const double *__restrict__ b, uint64_t n, double *__restrict__ partials) {
@@ -1249,11 +1348,11 @@ __device__ __forceinline__ double u01(uint64_t seed, uint64_t idx) {
     return (double(z >> 11) + 0.5) * (1.0 / 9007199254740992.0);
 }
 __global__ void __launch_bounds__(BLOCK)
-k_init_random(double *__restrict__ v, uint64_t n_vec, int Q, uint64_t seed, uint64_t salt) {
+k_init_random(double *__restrict__ v, uint64_t n_vec, int Q, uint64_t seed, uint64_t salt, uint64_t index0) {
     const uint64_t i = uint64_t(blockIdx.x) * BLOCK + threadIdx.x;
     if (i >= n_vec) return;
     double t[QMAX], norm = 0.0;
-    for (int q = 0; q < Q; ++q) { t[q] = u01(seed ^ salt, i * uint64_t(Q) + q); norm += t[q]; }
+    for (int q = 0; q < Q; ++q) { t[q] = u01(seed ^ salt, (index0 + i) * uint64_t(Q) + q); norm += t[q]; }
     for (int q = 0; q < Q; ++q) v[i * Q + q] = t[q] / norm;
 }
 

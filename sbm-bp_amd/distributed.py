@@ -1,0 +1,364 @@
+"""Multi-GPU BP: one process per GPU, vertex-range shards, torch.distributed (backend "nccl" = RCCL
+over xGMI) for the two exchanges a sweep needs:
+
+  * all-to-all of the boundary vertices' marginals, received straight into the tail of each
+    shard's marginal table (the marginal-gather sweep reads remote neighbours there);
+  * all-reduce of Q sums (global field) and one max (convergence hint) — and of one max for the
+    exact criterion when convergence is being decided.
+
+Everything between two collectives is a C-ABI shard step (include/sbmbp.h, sbmbp_shard_*).
+All collectives are issued on the stream the engine runs on, so a batch of sweeps is queued
+without host synchronisation; the device-side stop flag makes sweeps queued after the trigger
+no-ops. The orchestration is written over lists of local shards so that the same code drives
+one shard per rank (TorchDistComm) or several shards in one process (LocalComm: tests on one
+GPU, or on CPU with a stand-in backend).
+"""
+import ctypes as C
+
+import numpy as np
+
+from sbm_bp_amd.plan import ShardPlan, partition_rows
+
+HINT_SCALE = 8.0  # same rule as run_sweeps in csrc/engine.hip
+
+
+class ShardDesc(C.Structure):
+    _fields_ = [("n_global", C.c_uint32), ("n_own", C.c_uint32), ("n_halo", C.c_uint32), ("row0", C.c_uint32),
+                ("n_edges", C.c_uint64), ("edge0", C.c_uint64), ("row_ptr", C.POINTER(C.c_uint64)),
+                ("nbr_local", C.POINTER(C.c_uint32)), ("psi_buf0", C.c_void_p), ("psi_buf1", C.c_void_p),
+                ("red_buf", C.c_void_p)]
+
+
+class ConvState(C.Structure):
+    _fields_ = [("maxdiff", C.c_double), ("conv_iter", C.c_int), ("sweep_idx", C.c_int), ("stop", C.c_int),
+                ("reserved", C.c_int)]
+
+
+class HipShardBackend:
+    """one shard on one GPU: thin wrapper of the sbmbp_shard_* steps; buffers are torch tensors"""
+
+    def __init__(self, plan, Q, dc, device):
+        import torch
+        from sbm_bp_amd.capi import check, load_library
+        self._check, self._lib = check, load_library()
+        self.torch, self.plan, self.Q, self.dc = torch, plan, Q, dc
+        self.device = torch.device("cuda", device)
+        n_tab = plan.n_own + plan.n_halo
+        self.psi = torch.zeros((2, n_tab, Q), dtype=torch.float64, device=self.device)
+        self.red = torch.zeros(128, dtype=torch.float64, device=self.device)
+        self.send_idx = torch.as_tensor(plan.send_idx.astype(np.int32), device=self.device)
+        self.sendbuf = torch.zeros((max(1, len(plan.send_idx)), Q), dtype=torch.float64, device=self.device)
+        self._row_ptr = np.ascontiguousarray(plan.row_ptr, dtype=np.uint64)
+        self._nbr = np.ascontiguousarray(plan.nbr_local, dtype=np.uint32)
+        d = ShardDesc(plan.n_global, plan.n_own, plan.n_halo, plan.row0, plan.n_edges, plan.edge0,
+                      self._row_ptr.ctypes.data_as(C.POINTER(C.c_uint64)), self._nbr.ctypes.data_as(C.POINTER(C.c_uint32)),
+                      self.psi[0].data_ptr(), self.psi[1].data_ptr(), self.red.data_ptr())
+        h = C.c_void_p()
+        self._check(self._lib.sbmbp_shard_create(C.byref(h), C.byref(d), Q, dc, device))
+        self._h = h
+        # run on torch's current stream so kernels and collectives are ordered without host syncs
+        self._check(self._lib.sbmbp_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def __del__(self):
+        try:
+            self.torch.cuda.synchronize(self.device)
+            self._lib.sbmbp_destroy(self._h)
+        except Exception:
+            pass
+
+    def init_messages_device(self, seed, true_conf_local):
+        tc = np.ascontiguousarray(true_conf_local, dtype=np.uint32)
+        self._check(self._lib.sbmbp_init_messages_device(self._h, seed, tc.ctypes.data_as(C.POINTER(C.c_uint32))))
+
+    def set_params(self, cab, na, beta):
+        cab = np.ascontiguousarray(cab, dtype=np.float64)
+        na = np.ascontiguousarray(na, dtype=np.uint32)
+        self._check(self._lib.sbmbp_set_params(self._h, cab.ctypes.data_as(C.POINTER(C.c_double)),
+                                               na.ctypes.data_as(C.POINTER(C.c_uint32)), beta))
+
+    def begin(self, armed):
+        self._check(self._lib.sbmbp_shard_begin(self._h, armed))
+
+    def read_buffer(self, j):
+        return self._lib.sbmbp_shard_read_buffer(self._h, j)
+
+    def pack(self, j):
+        n = len(self.plan.send_idx)
+        if n:
+            self._check(self._lib.sbmbp_shard_pack(self._h, j, C.cast(self.send_idx.data_ptr(), C.POINTER(C.c_uint32)), n,
+                                                   C.cast(self.sendbuf.data_ptr(), C.POINTER(C.c_double))))
+
+    def field_partial(self, j):
+        self._check(self._lib.sbmbp_shard_field_partial(self._h, j))
+
+    def sweep_partial(self, j):
+        self._check(self._lib.sbmbp_shard_sweep_partial(self._h, j))
+
+    def finalize(self, mode):
+        self._check(self._lib.sbmbp_shard_finalize(self._h, mode))
+
+    def msgdiff_partial(self):
+        self._check(self._lib.sbmbp_shard_msgdiff_partial(self._h))
+
+    def rowsums_partial(self):
+        self._check(self._lib.sbmbp_shard_rowsums_partial(self._h))
+
+    def poll(self):
+        st = ConvState()
+        self._check(self._lib.sbmbp_shard_poll(self._h, C.byref(st)))
+        return st
+
+    def commit(self, n):
+        self._check(self._lib.sbmbp_shard_commit(self._h, n))
+
+    def rearm(self, armed):
+        self._check(self._lib.sbmbp_shard_rearm(self._h, armed))
+
+    def get_state(self):
+        from sbm_bp_amd.capi import c_dp
+        psi = np.zeros((self.plan.n_own, self.Q))
+        msg = np.zeros((self.plan.n_edges, self.Q))
+        self._check(self._lib.sbmbp_get_state(self._h, psi.ctypes.data_as(c_dp), msg.ctypes.data_as(c_dp)))
+        return psi, msg
+
+    def set_state(self, psi, msg):
+        from sbm_bp_amd.capi import c_dp
+        psi = np.ascontiguousarray(psi, dtype=np.float64)
+        msg = np.ascontiguousarray(msg, dtype=np.float64)
+        self._check(self._lib.sbmbp_set_state(self._h, psi.ctypes.data_as(c_dp), msg.ctypes.data_as(c_dp)))
+
+    def stats(self):
+        from sbm_bp_amd.capi import Stats
+        s = Stats()
+        self._check(self._lib.sbmbp_get_stats(self._h, C.byref(s)))
+        return s
+
+    def reset_stats(self):
+        self._check(self._lib.sbmbp_reset_stats(self._h))
+
+    def set_timing(self, on):
+        self._check(self._lib.sbmbp_set_timing(self._h, int(on)))
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+class TorchDistComm:
+    """one shard per rank; collectives over the default torch.distributed group"""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def local_ranks(self):
+        return [self.rank]
+
+    def all_to_all(self, recv_views, sendbufs, recv_counts, send_counts):
+        self.dist.all_to_all_single(recv_views[0], sendbufs[0], [int(x) for x in recv_counts[0]], [int(x) for x in send_counts[0]])
+
+    def all_reduce(self, tensors, op):
+        self.dist.all_reduce(tensors[0], op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX)
+
+
+class LocalComm:
+    """all shards live in this process (lock-step); collectives are tensor copies"""
+
+    def __init__(self, world):
+        self.rank, self.world = 0, world
+
+    def local_ranks(self):
+        return list(range(self.world))
+
+    def all_to_all(self, recv_views, sendbufs, recv_counts, send_counts):
+        send_off = [np.concatenate([[0], np.cumsum(sc)]) for sc in send_counts]
+        for r in range(self.world):
+            off = 0
+            for p in range(self.world):
+                n = int(recv_counts[r][p])
+                if n:
+                    assert int(send_counts[p][r]) == n
+                    s0 = int(send_off[p][r])
+                    recv_views[r][off:off + n].copy_(sendbufs[p][s0:s0 + n])
+                off += n
+
+    def all_reduce(self, tensors, op):
+        import torch
+        stack = torch.stack([t.to(tensors[0].device) for t in tensors])
+        red = stack.sum(0) if op == "sum" else stack.max(0).values
+        for t in tensors:
+            t.copy_(red.to(t.device))
+
+
+class ShardedBP:
+    """belief_propagation over vertex-range shards (infer path: converge / sweep / overlap)."""
+
+    def __init__(self, plans, Q, dc, comm, backend_factory=None):
+        self.comm, self.Q, self.dc = comm, Q, dc
+        self.plans = plans
+        if backend_factory is None:
+            import torch
+            dev = torch.cuda.current_device()
+            backend_factory = lambda plan: HipShardBackend(plan, Q, dc, dev)  # noqa: E731
+        self.shards = [backend_factory(p) for p in plans]
+        self.N_global = plans[0].n_global
+        self.E2_local = sum(p.n_edges for p in plans)
+        self.E2_global = None
+        self.total_sweeps = 0
+
+    # -- construction -------------------------------------------------------------------------
+    @classmethod
+    def from_csr(cls, row_ptr, nbr, Q, dc, comm, backend_factory=None):
+        bounds = partition_rows(row_ptr, comm.world)
+        plans = [ShardPlan(row_ptr, nbr, bounds, r) for r in comm.local_ranks()]
+        self = cls(plans, Q, dc, comm, backend_factory)
+        self.E2_global = int(len(nbr))
+        self.bounds = bounds
+        return self
+
+    @classmethod
+    def synthetic(cls, N, Q, c, eps, graph_seed, dc=0, seed=1234, comm=None):
+        """every rank generates the same planted-partition graph and keeps its own row range"""
+        import sbm_bp_amd as S
+        from sbm_bp_amd import synth
+        comm = comm or TorchDistComm()
+        pairs, cin, cout = synth.planted_partition(N, Q, c, eps, graph_seed)
+        g = S.Graph.from_edges(pairs, N)
+        del pairs
+        row_ptr, nbr, _ = g.csr()
+        self = cls.from_csr(row_ptr, nbr, Q, dc, comm)
+        tc = synth.true_conf(N, Q)
+        self.init_messages_device(seed, tc)
+        self.expand_bp_params(synth.cab_matrix(Q, cin, cout), np.array(synth.group_sizes(N, Q), dtype=np.uint32), 1.0)
+        return self
+
+    def init_messages_device(self, seed, true_conf_global):
+        for sh, p in zip(self.shards, self.plans):
+            sh.init_messages_device(seed, np.asarray(true_conf_global)[p.row0:p.row0 + p.n_own])
+
+    def expand_bp_params(self, cab, na, beta=1.0):
+        for sh in self.shards:
+            sh.set_params(cab, na, beta)
+
+    # -- one sweep = exchange, local sweep, reduce, finalize ------------------------------------
+    def _exchange(self, j):
+        for sh in self.shards:
+            sh.pack(j)
+        recv = [sh.psi[sh.read_buffer(j)][p.n_own:] for sh, p in zip(self.shards, self.plans)]
+        send = [sh.sendbuf[:len(p.send_idx)] for sh, p in zip(self.shards, self.plans)]
+        self.comm.all_to_all(recv, send, [p.recv_counts for p in self.plans], [p.send_counts for p in self.plans])
+
+    def _reduce(self, n_sum, n_max):
+        if n_sum:
+            self.comm.all_reduce([sh.red[:n_sum] for sh in self.shards], "sum")
+        if n_max:
+            self.comm.all_reduce([sh.red[n_sum:n_sum + n_max] for sh in self.shards], "max")
+
+    def _queue_sweep(self, j):
+        self._exchange(j)
+        for sh in self.shards:
+            sh.sweep_partial(j)
+        self._reduce(self.Q, 1)
+        for sh in self.shards:
+            sh.finalize(0)
+
+    def _begin(self, armed):
+        for sh in self.shards:
+            sh.begin(armed)
+            sh.field_partial(0)
+        self._reduce(self.Q, 0)
+        for sh in self.shards:
+            sh.finalize(1)
+
+    def _exact_diff(self):
+        for sh in self.shards:
+            sh.msgdiff_partial()
+        self._reduce(0, 1)
+        for sh in self.shards:
+            sh.sync()
+        return float(self.shards[0].red[0].item())
+
+    def _run(self, crit, max_sweeps, check_every, want_diff):
+        armed = HINT_SCALE * crit if crit > 0 else -1.0
+        self._begin(armed)
+        done, st = 0, None
+        while done < max_sweeps:
+            batch = min(check_every, max_sweeps - done)
+            for b in range(batch):
+                self._queue_sweep(done + b)
+            states = [sh.poll() for sh in self.shards]
+            st = states[0]
+            done += batch
+            if st.stop:
+                break
+        executed = st.sweep_idx if st is not None else 0
+        for sh in self.shards:
+            sh.commit(executed)
+        niter, exact = -1, None
+        if executed and (want_diff or (st.stop and crit > 0)):
+            exact = self._exact_diff()
+        if st is not None and st.stop and crit > 0:
+            if exact < crit:
+                niter = st.conv_iter
+            else:  # hint fired early: continue on the exact criterion, one sweep at a time
+                while executed < max_sweeps:
+                    for sh in self.shards:
+                        sh.rearm(-1.0)
+                    self._queue_sweep(0)
+                    for sh in self.shards:
+                        sh.poll()
+                        sh.commit(1)
+                    executed += 1
+                    exact = self._exact_diff()
+                    if exact < crit:
+                        niter = executed - 1
+                        break
+        self.total_sweeps += executed
+        return niter, exact
+
+    def sweep(self, n_sweeps=1, dumping_rate=1.0, want_diff=True):
+        if dumping_rate != 1.0:
+            raise NotImplementedError("sharded engines run the marginal-gather sweep: damping must be 1")
+        _, exact = self._run(-1.0, n_sweeps, max(64, n_sweeps), want_diff)
+        return exact
+
+    def converge(self, conv_crit, time_conv, dumping_rate=1.0, check_every=4):
+        if dumping_rate != 1.0:
+            raise NotImplementedError("sharded engines run the marginal-gather sweep: damping must be 1")
+        return self._run(conv_crit, time_conv, check_every, True)
+
+    # -- reductions over the marginals ------------------------------------------------------------
+    def _row_sums(self):
+        T = 2 * self.Q + self.Q * self.Q
+        for sh in self.shards:
+            sh.rowsums_partial()
+        self._reduce(T, 0)
+        for sh in self.shards:
+            sh.sync()
+        return self.shards[0].red[:T].cpu().numpy().copy()
+
+    def compute_overlap(self):
+        """compute_overlap (belief_propagation.cpp:775-811) from the all-reduced confusion matrix"""
+        import itertools
+        Q = self.Q
+        Cm = self._row_sums()[2 * Q:].reshape(Q, Q)
+        return max(sum(Cm[a, p[a]] for a in range(Q)) for p in itertools.permutations(range(Q))) / self.N_global
+
+    def na_expect(self):
+        return self._row_sums()[:self.Q]
+
+    def local_state(self):
+        return [sh.get_state() for sh in self.shards]
+
+    # -- bench plumbing ---------------------------------------------------------------------------
+    def stats(self):
+        s = self.shards[0].stats()
+        return s
+
+    def reset_stats(self):
+        for sh in self.shards:
+            sh.reset_stats()
+
+    def set_timing(self, on):
+        for sh in self.shards:
+            sh.set_timing(on)

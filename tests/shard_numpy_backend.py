@@ -1,0 +1,135 @@
+"""TEST INFRASTRUCTURE — numpy stand-in for one shard (same step interface as HipShardBackend in
+sbm-bp_amd/distributed.py) so the sharding plan, the halo exchange and the convergence driver of
+ShardedBP can be exercised on CPU (gloo, world_size 2) without a GPU. It restates the
+marginal-gather sweep of csrc/kernels.h (k_sweep_psi) with vectorised numpy; never shipped."""
+import numpy as np
+import torch
+
+
+class State:
+    def __init__(self):
+        self.maxdiff, self.conv_iter, self.sweep_idx, self.stop = 0.0, -1, 0, 0
+
+
+class NumpyShardBackend:
+    def __init__(self, plan, Q, dc):
+        self.plan, self.Q, self.dc = plan, Q, dc
+        n_tab = plan.n_own + plan.n_halo
+        self.psi = torch.zeros((2, n_tab, Q), dtype=torch.float64)
+        self.red = torch.zeros(128, dtype=torch.float64)
+        self.sendbuf = torch.zeros((max(1, len(plan.send_idx)), Q), dtype=torch.float64)
+        self.M = [np.zeros((plan.n_edges, Q)), np.zeros((plan.n_edges, Q))]
+        self.cur = self.pcur = 0
+        self.st = State()
+        self.src = np.repeat(np.arange(plan.n_own), plan.deg)
+        self.armed = -1.0
+
+    # -- state -----------------------------------------------------------------------------------
+    def set_state(self, psi, msg):
+        self.psi[self.pcur][:self.plan.n_own] = torch.from_numpy(np.asarray(psi, dtype=np.float64))
+        self.M[0][:] = msg  # (psi^0, m^-1): sweep 0 reads the buffer it then overwrites
+        self.M[1][:] = msg
+
+    def get_state(self):
+        return self.psi[self.pcur][:self.plan.n_own].numpy().copy(), self.M[self.cur].copy()
+
+    def set_params(self, cab, na, beta):
+        self.cab = np.asarray(cab, dtype=np.float64)
+        self.W = self.cab ** beta if self.dc == 0 else self.cab
+        self.eta = np.asarray(na, dtype=np.float64) / self.plan.n_global
+        self.beta = beta
+
+    # -- steps -------------------------------------------------------------------------------------
+    def begin(self, armed):
+        self.armed = armed
+        self.st = State()
+
+    def rearm(self, armed):
+        self.armed = armed
+        self.st.stop, self.st.conv_iter = 0, -1
+
+    def read_buffer(self, j):
+        return (self.pcur + j) & 1
+
+    def pack(self, j):
+        n = len(self.plan.send_idx)
+        if n:
+            self.sendbuf[:n] = self.psi[self.read_buffer(j)][torch.from_numpy(self.plan.send_idx)]
+
+    def _g(self):
+        return self.plan.deg.astype(np.float64) if self.dc else np.ones(self.plan.n_own)
+
+    def field_partial(self, j):
+        p = self.psi[self.read_buffer(j)][:self.plan.n_own].numpy()
+        self.red[:self.Q] = torch.from_numpy((self._g()[:, None] * p).sum(0))
+
+    def sweep_partial(self, j):
+        if self.st.stop:
+            return
+        pl = self.plan
+        Mio = self.M[((self.cur + j) & 1) ^ 1]
+        pold = self.psi[(self.pcur + j) & 1].numpy()
+        pnew = self.psi[((self.pcur + j) & 1) ^ 1].numpy()
+        bo = Mio @ self.W
+        inc = pold[pl.nbr_local.astype(np.int64)] / bo
+        inc /= inc.sum(1, keepdims=True)
+        logb = np.log(inc @ self.W)
+        logA = np.zeros((pl.n_own, self.Q))
+        np.add.at(logA, self.src, logb)
+        if self.dc == 0:
+            fac = np.log(self.eta) - self.beta * self.hN
+            logA += fac[None, :]
+        else:
+            logA += np.log(self.eta)[None, :] - pl.deg[:, None] * self.hN[None, :]
+        A = np.exp(logA - logA.max(1, keepdims=True))
+        psi_new = A / A.sum(1, keepdims=True)
+        cav = logA[self.src] - logb
+        cav = np.exp(cav - cav.max(1, keepdims=True))
+        new = cav / cav.sum(1, keepdims=True)
+        md = float(np.abs(new - Mio).max()) if len(new) else 0.0
+        Mio[:] = new
+        pnew[:pl.n_own] = psi_new
+        self.red[:self.Q] = torch.from_numpy((self._g()[:, None] * psi_new).sum(0))
+        self.red[self.Q] = md
+
+    def finalize(self, mode):
+        if mode == 0 and self.st.stop:
+            return
+        S = self.red[:self.Q].numpy().copy()
+        h = self.cab.T @ S
+        self.hN = h / self.plan.n_global
+        if mode == 0:
+            md = float(self.red[self.Q])
+            self.st.maxdiff = md
+            if md < self.armed and self.st.conv_iter < 0:
+                self.st.conv_iter, self.st.stop = self.st.sweep_idx, 1
+            self.st.sweep_idx += 1
+
+    def msgdiff_partial(self):
+        self.red[0] = float(np.abs(self.M[0] - self.M[1]).max()) if self.plan.n_edges else 0.0
+
+    def rowsums_partial(self):
+        Q = self.Q
+        p = self.psi[self.pcur][:self.plan.n_own].numpy()
+        out = np.zeros(2 * Q + Q * Q)
+        out[:Q] = p.sum(0)
+        out[Q:2 * Q] = (self.plan.deg[:, None] * p).sum(0)
+        for a in range(Q):
+            out[2 * Q + a * Q:2 * Q + (a + 1) * Q] = p[self.true_conf == a].sum(0)
+        self.red[:len(out)] = torch.from_numpy(out)
+
+    def poll(self):
+        import copy
+        return copy.copy(self.st)
+
+    def commit(self, n):
+        self.cur = (self.cur + n) & 1
+        self.pcur = (self.pcur + n) & 1
+
+    def sync(self):
+        pass
+
+    def init_from_global(self, psi_global, msg_global, true_conf_global):
+        p = self.plan
+        self.set_state(psi_global[p.row0:p.row0 + p.n_own], msg_global[p.edge0:p.edge0 + p.n_edges])
+        self.true_conf = np.asarray(true_conf_global)[p.row0:p.row0 + p.n_own]

@@ -1,0 +1,116 @@
+"""GPU tier for the sharded engine: several HIP shards in one process on one GPU (LocalComm), checked
+against the unsharded run and the reference goldens; plus hub rows (degree above the segment
+capacity) through both forms of the hub kernel."""
+import numpy as np
+import pytest
+
+from conftest import args_of, best_perm_diff, golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(orc, name):
+    gd = golden(name)
+    a, r = args_of(gd), gd["result"]
+    g = orc.Graph.from_edgelist(a["path"], a["N"])
+    bp = orc.OracleBP(g, a["Q"], a["dc"])
+    bp.init_messages(0, None, a["true_conf"], orc.Rng(a["seed"]))
+    cab, na = orc.param_from_direct(a["N"], a["Q"], a["pa"], a["cab_upper"])
+    psi0, msg0 = bp.get_state()
+    return a, r, g, cab, na, psi0, msg0
+
+
+def _sharded(g, a, cab, na, psi0, msg0, world):
+    from sbm_bp_amd.distributed import LocalComm, ShardedBP
+    sb = ShardedBP.from_csr(g.row_ptr, g.nbr, a["Q"], a["dc"], LocalComm(world))
+    sb.init_messages_device(7, a["true_conf"])
+    for sh, p in zip(sb.shards, sb.plans):
+        sh.set_state(psi0[p.row0:p.row0 + p.n_own], msg0[p.edge0:p.edge0 + p.n_edges])
+    sb.expand_bp_params(cab, na, a["beta"])
+    return sb
+
+
+@pytest.mark.parametrize("name,world", [("c1_matched_tight_seed0", 2), ("c1_matched_tight_seed0", 5), ("q4_tight_seed0", 3),
+                                        ("c1_dc1_tight_seed0", 4)])
+def test_sharded_equals_unsharded_and_reference(orc, name, world):
+    a, r, g, cab, na, psi0, msg0 = _problem(orc, name)
+    one = _sharded(g, a, cab, na, psi0, msg0, 1)
+    sb = _sharded(g, a, cab, na, psi0, msg0, world)
+    for _ in range(2):
+        d1, dk = one.sweep(3), sb.sweep(3)
+        assert abs(d1 - dk) < 1e-13
+        psi_k = np.concatenate([s[0] for s in sb.local_state()])
+        msg_k = np.concatenate([s[1] for s in sb.local_state()])
+        psi_1, msg_1 = one.local_state()[0]
+        # partition invariance: only the reduction order of the Q field sums differs
+        assert np.abs(psi_k - psi_1).max() < 1e-12 and np.abs(msg_k - msg_1).max() < 1e-12
+    niter, exact = sb.converge(1e-12, 3000, 1.0, check_every=6)
+    assert niter >= 0 and exact < 1e-12
+    assert one.converge(1e-12, 3000, 1.0, check_every=1)[0] == niter
+    psi = np.concatenate([s[0] for s in sb.local_state()])
+    d, _ = best_perm_diff(psi, np.array(r["psi"]).reshape(psi.shape))
+    assert d < 1e-9  # the reference's fixed point
+    assert abs(sb.compute_overlap() - r["overlap"]) < 1e-9
+    assert sb.shards[0].stats().psi_form_sweeps > 0
+
+
+def test_sharded_matches_single_engine_fixed_point(S, orc):
+    a, r, g, cab, na, psi0, msg0 = _problem(orc, "q4_tight_seed0")
+    sb = _sharded(g, a, cab, na, psi0, msg0, 3)
+    sb.converge(1e-12, 3000, 1.0)
+    psi = np.concatenate([s[0] for s in sb.local_state()])
+    gg = S.load_edge_list(a["path"], a["N"])
+    bp = S.bp_conditional()
+    bp.init_messages(S.blockmodel_t(gg, a["Q"], 0), 0, None, a["true_conf"], a["seed"])
+    bp.expand_bp_params(S.bp_blockmodel_state(cab, na))
+    bp.converge(1e-12, 3000, 1.0)
+    assert best_perm_diff(psi, bp.real_psi())[0] < 1e-9
+
+
+@pytest.fixture(scope="module")
+def S():
+    import sbm_bp_amd as S
+    S.load_library()
+    return S
+
+
+def _hub_graph(N, hub_deg, seed):
+    rng = np.random.default_rng(seed)
+    e = [np.stack([np.zeros(hub_deg, dtype=np.int64), rng.choice(np.arange(1, N), hub_deg, replace=False)], 1),
+         np.stack([np.full(hub_deg - 300, 1, dtype=np.int64), rng.choice(np.arange(2, N), hub_deg - 300, replace=False)], 1),
+         rng.integers(0, N, size=(3 * N, 2))]
+    return np.concatenate(e).astype(np.uint32)
+
+
+@pytest.mark.parametrize("Q,dc", [(3, 1), (2, 0), (4, 1)])
+def test_hub_rows_both_forms_and_oracle(S, orc, Q, dc):
+    """rows above the segment capacity (512 edges, 1024 for Q=2) take the workgroup-per-row kernels"""
+    N = 6000
+    pairs = _hub_graph(N, 1700, 3)
+    g = S.Graph.from_edges(pairs, N)
+    og = orc.Graph.from_edges(pairs, N)
+    assert g.max_degree > 1024
+    tc = (np.arange(N) * Q // N).astype(np.uint32)
+    cab = np.full((Q, Q), 0.004 if dc else 1.0) + np.eye(Q) * (0.02 if dc else 5.0)
+    na = np.array([N // Q] * Q, dtype=np.uint32)
+    res = []
+    for mode in (0, 1):
+        bp = S.bp_conditional()
+        bp.init_messages(S.blockmodel_t(g, Q, dc), 0, None, tc, 11)
+        bp.expand_bp_params(S.bp_blockmodel_state(cab, na))
+        bp.set_gather_mode(mode)
+        assert bp.stats().n_hub_rows >= 2
+        d = [bp.sweep(1, 1.0) for _ in range(4)]
+        res.append((d, bp.get_state(), bp.compute_free_energy(parts=True)[1], bp.stats().psi_form_sweeps))
+    obp = orc.OracleBP(og, Q, dc)
+    obp.init_messages(0, None, tc, orc.Rng(11))
+    obp.set_params(cab, na, 1.0)
+    od = [obp.sweep_sync(1.0) for _ in range(4)]
+    opsi, omsg = obp.get_state()
+    obp.compute_h()
+    _, oparts = obp.free_energy(0)
+    assert res[0][3] == 3 and res[1][3] == 0
+    for d, (psi, msg), parts, _ in res:
+        assert np.abs(np.array(d) - np.array(od)).max() < 1e-11
+        assert np.abs(psi - opsi).max() < 1e-11 and np.abs(msg - omsg).max() < 1e-11
+        assert np.abs(parts - oparts).max() < 1e-9 * max(1.0, np.abs(oparts).max())
