@@ -1,0 +1,129 @@
+"""bin/bp: the process-level drop-in boundary (flags, stdout/stderr lines and return codes of
+the reference's main.cpp:85-365). CPU tier: argument handling; GPU tier: the README commands."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden, gpath
+
+BP = os.path.join(ROOT, "bin", "bp")
+DS = gpath("c1_dataset.edgelist")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    import sbm_bp_amd as S
+    S.build_all()
+    assert os.path.exists(BP)
+
+
+def run(*args):
+    p = subprocess.run([BP] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+    return p.returncode, p.stdout, p.stderr
+
+
+def test_help_and_required_flags():
+    rc, out, err = run()
+    assert rc == 0 and "BP algorithms for the SBM (final output only)" in err and out == ""  # main.cpp:154-160
+    rc, out, err = run("-h")
+    assert rc == 0 and "--edge_list_path" in err
+    assert run("-m", "infer", "-n", 500, 500)[::2] == (1, "edge_list_path is required (-e flag)\n")  # :162-165 (sic)
+    assert run("-l", DS, "-n", 500, 500)[::2] == (1, "mode is required (-m flag)\n")
+    assert run("-l", DS, "-m", "infer")[::2] == (1, "n is required (-n flag)\n")
+
+
+def test_parameter_selection_errors():
+    base = ["-l", DS, "-n", 500, 500, "-m", "infer"]
+    assert run(*base)[::2] == (1, "Error! Please just input both pa/cab parameters.\n")  # :199-201
+    assert run(*base, "--pa", 0.5, 0.5)[::2] == (1, "Error! Please just input both pa/cab parameters.\n")
+    rc, _, err = run(*base, "--epsilon_c", 0.1, 3, "--pa", 0.5, 0.5, "--cab", 1, 2, 3)
+    assert (rc, err) == (1, "Error! Please just choose one way to initialize the pa/cab parameter.\n")  # :196-198
+    rc, _, err = run(*base, "--epsilon_c", 0.1, 3, "-i", 1)
+    assert (rc, err) == (1, "Error! Please assign the file path of the initial belief of node membership.\n")  # :208-213
+    rc, _, err = run(*base, "--mb_n", "--mb", 0, 1, "--epsilon_c", 0.1, 3)
+    assert (rc, err) == (1, "Error! Please just select one option to assign the membership vector.\n")  # :178-180
+    rc, _, err = run("--no_such_flag")
+    assert rc == 1 and "unrecognised option" in err
+
+
+def test_option_syntax_variants_and_silent_modes():
+    # --opt=value, short options, negative multitoken values, an unknown --mode does nothing and returns 0 (:361-365)
+    rc, out, err = run("--edge_list_path=" + DS, "-n", 500, 500, "--epsilon_c", -1, 3, "--mode=neither", "-d0", "-t", 10)
+    assert rc == 0 and out == ""
+    assert err == "Randomly assign initial messages!\nWarning! Assign true conf using ordered node membership.\n"
+    rc, out, err = run("-l", DS, "-n", 500, 500, "--epsilon_c", 0.1, 3, "-m", "neither", "-f", 1, 2, 3)
+    assert rc == 0 and err.startswith("Randomly assign initial messages, except certain fixed nodes.\n")  # :214-215
+
+
+def test_missing_edgelist_fails_loudly():
+    rc, out, err = run("-l", "/nonexistent/file", "-n", 500, 500, "--epsilon_c", 0.1, 3, "-m", "infer")
+    assert rc == 1 and "cannot open edge list" in err  # documented deviation from SURVEY B14
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    rc, out, err = run("-l", DS, "-n", 500, 500, "--epsilon_c", 0.1, 3, "-m", "infer")
+    assert rc == 1 and out == "" and "no CPU fallback" in err
+
+
+@pytest.mark.gpu
+def test_readme_infer_command():
+    """README.md:36 — reference stdout `2.99556 -0.143476 0.5 32` (niter is schedule dependent)"""
+    rc, out, err = run("-l", DS, "-n", 500, 500, "--pa", 0.5, 0.5, "--cab", 3.63, 2.36, 3.63, "-t", 1000, "-i", 0, "-m", "infer", "-d", 0)
+    assert rc == 0
+    assert err == "Randomly assign initial messages!\nWarning! Assign true conf using ordered node membership.\n"
+    assert out.endswith(" \n") and out.count("\n") == 1  # trailing space before the newline (bp.cpp:88)
+    tok = out.split()
+    assert tok[0] == "2.99556" and tok[1] == "-0.143476" and abs(float(tok[2]) - 0.5) < 1e-5 and 5 <= int(tok[3]) <= 60
+
+
+@pytest.mark.gpu
+def test_readme_learn_command():
+    """README.md:41 — reference stdout `0.5 0.5` / `3.63024 2.36016` / `2.36016 3.63024`, stderr `overlap:0.5`"""
+    g = golden("c1_readme_learn_seed0")["result"]
+    rc, out, err = run("-l", DS, "-n", 500, 500, "--pa", 0.5, 0.5, "--cab", 3.63, 2.36, 3.63, "-t", 1000, "-i", 0, "-m", "learn", "-d", 0)
+    assert rc == 0
+    lines = out.split("\n")
+    assert len(lines) == 4 and lines[3] == "" and lines[0].endswith(" ")
+    # eta moves in steps of 1/N because learning_step truncates na to integers (bp.cpp:58-63); at the
+    # symmetric fixed point na_expect = 500 +- 1e-7, so the truncation may land on 499 or 500 depending on the schedule
+    assert np.abs(np.array([float(x) for x in lines[0].split()]) - 0.5).max() <= 2.0 / 1000 + 1e-12
+    got = np.array([[float(x) for x in lines[1].split()], [float(x) for x in lines[2].split()]])
+    assert np.abs(got - np.array(g["cab_final"]).reshape(2, 2)).max() < 2e-3
+    assert "Algorithm stop because of fdiff < learning_conv_crit. [which is good]\n" in err
+    ov = [l for l in err.split("\n") if l.startswith("overlap:")]
+    assert len(ov) == 1 and abs(float(ov[0][8:]) - 0.5) < 1e-3
+
+
+@pytest.mark.gpu
+def test_matched_parameters_precision_and_marginals(tmp_path):
+    g = golden("c1_matched_tight_seed0")["result"]
+    mj = tmp_path / "m.json"
+    rc, out, err = run("-l", DS, "-n", 500, 500, "--epsilon_c", 0.1, 3.0, "-t", 2000, "-m", "infer", "-d", 0, "-e", 1e-13,
+                       "--precision", 15, "--if_output_marginals", "--metrics_json", mj)
+    assert rc == 0
+    lines = out.split("\n")
+    e, f, ov, niter = lines[0].split()
+    assert abs(float(f) - g["f"]) < 1e-9 and abs(float(e) - g["e"]) < 1e-9 and abs(float(ov) - g["overlap"]) < 1e-9
+    psi = np.array([[float(x) for x in l.split()] for l in lines[1:1001]])
+    ref = np.array(g["psi"]).reshape(1000, 2)
+    assert min(np.abs(psi - ref).max(), np.abs(psi[:, ::-1] - ref).max()) < 1e-9
+    assert err.count("margEntropy H(v) is") == 1000  # per-node entropies on clog (bp.cpp:95-97)
+    m = json.load(open(mj))
+    assert m["sweeps"] == int(niter) + 1 and m["marginal_gather_sweeps"] == m["sweeps"] - 1
+
+
+@pytest.mark.gpu
+def test_degree_corrected_run_prints_minus_nan_entropy():
+    g = golden("c1_dc1_default_seed0")["result"]
+    rc, out, err = run("-l", DS, "-n", 500, 500, "--pa", 0.5, 0.5, "--cab", 0.60606060606060608, 0.060606060606060608,
+                       0.60606060606060608, "-t", 1000, "-m", "infer", "-d", 0, "--deg_corr_flag", 1)
+    assert rc == 0
+    tok = out.split()
+    assert tok[0] == "-nan"  # the reference prints -nan for deg_corr_flag != 0
+    assert abs(float(tok[1]) - g["f"]) < 1e-5 and abs(float(tok[2]) - g["overlap"]) < 1e-4

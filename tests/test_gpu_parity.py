@@ -171,7 +171,7 @@ def test_em_expectations_on_fixed_point(S, name):
     assert np.abs(cab[np.ix_(p, p)] - ref_cab).max() < 1e-8 * max(1.0, np.abs(ref_cab).max())
 
 
-@pytest.mark.parametrize("name", ["c1_learn_515_seed0", "q4_learn_seed2"])
+@pytest.mark.parametrize("name", ["c1_learn_515_seed0", "q4_learn_seed2", "c1_readme_learn_seed0"])
 def test_learning_matches_synchronous_oracle(S, orc, name):
     """EM trajectories depend on the schedule; the engine must follow the oracle's synchronous EM run
     step for step and end near the reference's (asynchronous) learned parameters."""
@@ -186,7 +186,7 @@ def test_learning_matches_synchronous_oracle(S, orc, name):
     assert res.em_steps == steps and list(na) == list(ona)
     # EM amplifies rounding differences over tens of steps: 1e-6 relative, far inside the north star's 1e-5
     assert np.abs(cab - ocab).max() < 1e-6 * np.abs(ocab).max() and abs(res.free_energy - f) < 1e-8
-    if name.startswith("c1_"):
+    if name == "c1_learn_515_seed0":
         # well-posed start: the synchronous EM run ends next to the reference's asynchronous one. (From a
         # poor start — q4_learn_seed2 — EM is trajectory dependent and the schedules reach different
         # local optima; there only the oracle parity above is meaningful.)
