@@ -32,6 +32,8 @@ WORKLOADS = {
     "C2": (1_000_000, 2, 3.0, 0.1, 0, 1),
     "C5": (1_000_000, 4, 5.0, 0.1, 0, 4),
     "small": (200_000, 4, 10.0, 0.1, 0, 9),
+    # degree-corrected SBM, power-law propensities, --deg_corr_flag 1 (hub rows take the workgroup-per-row kernel)
+    "C4": (1_000_000, 8, 8.0, 0.1, 1, 3),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -72,6 +74,27 @@ def cpu_baseline(Q, c, eps, sample_n=200_000, sweeps=8):
     return {"value": sweeps * g.E2 / dt, "unit": "edge-msg/s", "cores": 1, "kind": "port", "sample": sample}
 
 
+def pmc_traffic(workload, kernel, n_gpus, E2, N, Q):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC summary of the same command
+    (profiles/*_pmc_*.json; bench.py cannot collect PMC counters itself). Corrected as
+    MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 wide coalesced
+    streaming reads are tallied at half (128-B requests counted as 64 B), random 32-B gathers cost one
+    64-B request each and are counted in full; writes read exactly. See DESIGN.md §4."""
+    import glob
+    if n_gpus != 1:
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("kernel") == kernel and d.get("workload", "").startswith(workload + " "):
+            c = d["counters"]
+            stream_reads = E2 * (8.0 * Q + 4.0) + N * 4.0  # own old message + index per edge, row offsets
+            return c["FETCH_SIZE"]["per_launch_mean"] * 1024.0 + 0.5 * stream_reads + c["WRITE_SIZE"]["per_launch_mean"] * 1024.0
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,13 +132,17 @@ def main():
     N, Q, c, eps, dc, gseed = WORKLOADS[args.workload]
     t0 = time.perf_counter()
     if not sharded:
-        pairs, cin, cout = synth.planted_partition(N, Q, c, eps, gseed)
+        if args.workload == "C4":
+            pairs, cab_mat, c_eff = synth.dc_sbm_powerlaw(N, Q, c, eps, gseed)
+        else:
+            pairs, cin, cout = synth.planted_partition(N, Q, c, eps, gseed)
+            cab_mat = synth.cab_matrix(Q, cin, cout)
         g = S.Graph.from_edges(pairs, N)
         del pairs
         bm = S.blockmodel_t(g, Q, dc)
         bp = S.bp_conditional(device=local_rank)
         bp.init_messages_device(bm, synth.true_conf(N, Q), 1234)
-        bp.expand_bp_params(S.bp_blockmodel_state(synth.cab_matrix(Q, cin, cout), np.array(synth.group_sizes(N, Q), dtype=np.uint32)))
+        bp.expand_bp_params(S.bp_blockmodel_state(cab_mat, np.array(synth.group_sizes(N, Q), dtype=np.uint32)))
         if args.gather == "messages":
             bp.set_gather_mode(1)
         E2_total = g.E2
@@ -156,21 +183,23 @@ def main():
         sweeps_to_converge = (args.warmup + args.steps + niter + 1) if niter >= 0 else -1
 
     if rank == 0:
+        kname = ("k_sweep_psi<%d>" if st.psi_form_sweeps else "k_sweep<%d>") % Q
         out = {
             "metric": "BP edge-message updates/sec", "value": args.steps * E2_total / dt, "unit": "edge-msg/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: planted SBM N=%d Q=%d c=%g eps=%g deg_corr=%d, synchronous BP sweep (-m infer inner loop)" % (
-                args.workload, N, Q, c, eps, dc), "N": N, "Q": Q, "E2": int(E2_total), "parallelism": "vertex-range shards x%d%s" % (world, " (sharded driver)" if sharded else ""),
+                args.workload, N, Q, c, eps, dc), "N": N, "Q": Q, "E2": int(E2_total), "hub_rows": int(st.n_hub_rows), "parallelism": "vertex-range shards x%d%s" % (world, " (sharded driver)" if sharded else ""),
                 "setup_s": round(setup_s, 2)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": ("k_sweep_psi<%d>" if st.psi_form_sweeps else "k_sweep<%d>") % Q, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(args.workload, kname, world, E2_total, N, Q),
+                         "kernel": kname, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if sweeps_to_converge is not None:
             out["sweeps_to_converge"] = sweeps_to_converge
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(Q, c, eps)
+            out["cpu_baseline"] = cpu_baseline(Q, c, eps)  # plain planted partition of the same Q, c (also for C4)
         print(json.dumps(out), flush=True)
     if sharded:
         dist.barrier()

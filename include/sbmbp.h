@@ -221,8 +221,10 @@ int sbmbp_shard_read_buffer(sbmbp_engine_t *e, uint32_t j);
 int sbmbp_shard_field_partial(sbmbp_engine_t *e, uint32_t j);
 /* sweep j over the owned rows; red[0..Q) = partial sums of the new marginals, red[Q] = hint */
 int sbmbp_shard_sweep_partial(sbmbp_engine_t *e, uint32_t j);
-/* consume red (already all-reduced by the caller): mode 0 after a sweep, 1 field initialisation */
-int sbmbp_shard_finalize(sbmbp_engine_t *e, int mode);
+/* consume the reduction values: n_rows rows of (Q+1) doubles starting at red + 16 (the caller
+ * all-gathers every shard's red[0..Q] there; n_rows = number of shards). Rows are folded in order —
+ * sums for the Q field entries, max for the hint. mode 0 after a sweep, 1 field initialisation */
+int sbmbp_shard_finalize(sbmbp_engine_t *e, int mode, uint32_t n_rows);
 /* red[0] = max |m_a - m_b| over the two message buffers of this shard (exact 1-step criterion) */
 int sbmbp_shard_msgdiff_partial(sbmbp_engine_t *e);
 /* red[0..2Q+Q*Q) = na_expect, nna_expect, confusion sums over the owned rows (current marginals) */

@@ -419,8 +419,11 @@ double sweep_sync(bp_t &s, double damp) {
             if (amax > 0.0 && (amax < 1e-100 || amax > 1e100)) for (uint32_t q = 0; q < Q; ++q) A[q] /= amax;
         }
         double tot = 0.0;
+        // dc != 0: exp(-d_i h/N) underflows in every component for hub rows; shifting by min_q h changes only a
+        // common factor (the reference's large-degree path works in the log domain with a max-shift, :850-868)
+        double hmin = *std::min_element(s.h.begin(), s.h.end());
         for (uint32_t q = 0; q < Q; ++q) {
-            double F = (s.dc == 0) ? s.exph[q] : std::exp(-di * s.h[q] / s.N);
+            double F = (s.dc == 0) ? s.exph[q] : std::exp(-di * (s.h[q] - hmin) / s.N);
             A[q] = A[q] * s.eta[q] * F;
             tot += A[q];
         }
@@ -431,7 +434,7 @@ double sweep_sync(bp_t &s, double damp) {
                 double bq = b[size_t(l) * Q + q];
                 if (bq > 0.0 && A[q] / bq < std::numeric_limits<double>::infinity()) cav[q] = A[q] / bq;
                 else {  // exact cavity product when the division is not usable
-                    double p = s.eta[q] * ((s.dc == 0) ? s.exph[q] : std::exp(-di * s.h[q] / s.N));
+                    double p = s.eta[q] * ((s.dc == 0) ? s.exph[q] : std::exp(-di * (s.h[q] - hmin) / s.N));
                     for (uint32_t lx = 0; lx < d; ++lx) if (lx != l) p *= b[size_t(lx) * Q + q];
                     cav[q] = p;
                 }

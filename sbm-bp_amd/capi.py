@@ -80,7 +80,7 @@ SYMBOLS = {
     "sbmbp_shard_read_buffer": (C.c_int, [C.c_void_p, C.c_uint32]),
     "sbmbp_shard_field_partial": (C.c_int, [C.c_void_p, C.c_uint32]),
     "sbmbp_shard_sweep_partial": (C.c_int, [C.c_void_p, C.c_uint32]),
-    "sbmbp_shard_finalize": (C.c_int, [C.c_void_p, C.c_int]),
+    "sbmbp_shard_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
     "sbmbp_shard_msgdiff_partial": (C.c_int, [C.c_void_p]),
     "sbmbp_shard_rowsums_partial": (C.c_int, [C.c_void_p]),
     "sbmbp_shard_poll": (C.c_int, [C.c_void_p, C.c_void_p]),

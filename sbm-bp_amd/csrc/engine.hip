@@ -1185,7 +1185,7 @@ int sbmbp_shard_field_partial(sbmbp_engine_t *e, uint32_t j) {
     DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_psi_sum<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
                                         e->d_psi[(e->pcur + int(j)) & 1], e->N, rows_per_blk, int(e->dc != 0), e->d_partials));
     hipLaunchKernelGGL(k_fold_stage, dim3(1), dim3(BLOCK), 0, e->stream, e->d_partials, nb, nb, int(e->Q), 1, e->Q + 1, e->d_red);
-    HIPCHK(hipGetLastError());
+    HIPCHK(hipGetLastError());  // k_psi_sum writes 0 into the max column, so red[Q] = 0
     return SBMBP_OK;
 }
 
@@ -1221,10 +1221,10 @@ int sbmbp_shard_sweep_partial(sbmbp_engine_t *e, uint32_t j) {
     return SBMBP_OK;
 }
 
-int sbmbp_shard_finalize(sbmbp_engine_t *e, int mode) {
+int sbmbp_shard_finalize(sbmbp_engine_t *e, int mode, uint32_t n_rows) {
     IS_SHARD(e);
-    if (mode != 0 && mode != 1) return SBMBP_ERR_ARG;
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, e->stream, e->d_red, 1u, int(e->Q), mode, e->d_P, e->d_hist, e->hist_cap);
+    if ((mode != 0 && mode != 1) || n_rows == 0 || 16 + uint64_t(n_rows) * (e->Q + 1) > 128) return SBMBP_ERR_ARG;
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, e->stream, e->d_red + 16, n_rows, int(e->Q), mode, e->d_P, e->d_hist, e->hist_cap);
     HIPCHK(hipGetLastError());
     return SBMBP_OK;
 }

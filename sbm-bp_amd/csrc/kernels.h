@@ -180,6 +180,50 @@ template <int Q> __device__ __forceinline__ int rescale_pow2(double (&A)[Q]) {
     return n;
 }
 
+// A[q] <- A[q] * eta[q] * F_i[q] up to a common factor, and their sum. F_i = exp(-beta h/N) (dc 0,
+// pre-multiplied into etaF) or exp(-d_i h[q]/N) (dc 1, 2; bp.cpp:1021-1023). For large degrees the
+// latter underflows in every component, so it is shifted by min_q h (cancels in both normalisations)
+// and, when the spread is still extreme, combined in the log domain with a max-shift exactly as the
+// reference's large-degree path does (bp.cpp:850-868).
+template <int Q>
+__device__ __forceinline__ double apply_field(const dev_params *__restrict__ P, int dc, double di, double (&A)[Q]) {
+    double tot = 0.0;
+    if (!dc) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { A[q] *= P->etaF[q]; tot += A[q]; }
+        return tot;
+    }
+    double hmin = P->hN[0], hmax = P->hN[0];
+#pragma unroll
+    for (int q = 1; q < Q; ++q) { hmin = fmin(hmin, P->hN[q]); hmax = fmax(hmax, P->hN[q]); }
+    if (di * (hmax - hmin) < 300.0) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { A[q] *= P->eta[q] * exp(-di * (P->hN[q] - hmin)); tot += A[q]; }
+    } else {
+        double lp[Q], m = -1.0e300;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { lp[q] = log(A[q]) + P->logeta[q] - di * P->hN[q]; m = fmax(m, lp[q]); }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { A[q] = exp(lp[q] - m); tot += A[q]; }
+    }
+    return tot;
+}
+
+// log( sum_q A[q] eta[q] F_i[q] ) with A carrying a removed power-of-two exponent ex (f_site, bp.cpp:446-502)
+template <int Q>
+__device__ __forceinline__ double log_partition(const dev_params *__restrict__ P, int dc, double di, const double (&A)[Q], int ex) {
+    double lp[Q], m = -1.0e300;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        lp[q] = log(A[q]) + P->logeta[q] - (dc ? di : P->beta) * P->hN[q];
+        m = fmax(m, lp[q]);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) s += exp(lp[q] - m);
+    return m + log(s) + double(ex) * 0.6931471805599453;
+}
+
 // b[q] = sum_t W_il[t][q] m[t]   (belief_propagation.cpp:1000-1012)
 template <int Q, bool DC2>
 __device__ __forceinline__ void edge_field(const dev_params *__restrict__ P, const double (&m)[Q], double didl, double (&b)[Q]) {
@@ -292,13 +336,7 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
                 for (int q = 0; q < Q; ++q) A[q] *= b[q];
                 rescale_pow2<Q>(A);
             }
-            double tot = 0.0;
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const double fac = dc ? P->eta[q] * exp(-di * P->hN[q]) : P->etaF[q];
-                A[q] *= fac;
-                tot += A[q];
-            }
+            const double tot = apply_field<Q>(P, dc, di, A);
             store_vec<Q>(&sA[r * Q], A);
             const double inv = 1.0 / tot;
 #pragma unroll
@@ -336,17 +374,15 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
                 if (!ok) {  // exact cavity product when a division is unusable (b == 0 or overflow)
                     const int es = int(srp[r]), ee = int(srp[r + 1]);
                     const double di = double(ee - es);
-                    tot = 0.0;
 #pragma unroll
-                    for (int q = 0; q < Q; ++q) cav[q] = dc ? P->eta[q] * exp(-di * P->hN[q]) : P->etaF[q];
+                    for (int q = 0; q < Q; ++q) cav[q] = 1.0;
                     for (int e = es; e < ee; ++e) {
                         if (e == le) continue;
 #pragma unroll
                         for (int q = 0; q < Q; ++q) cav[q] *= sb[e * Q + q];
                         rescale_pow2<Q>(cav);
                     }
-#pragma unroll
-                    for (int q = 0; q < Q; ++q) tot += cav[q];
+                    tot = apply_field<Q>(P, dc, di, cav);
                 }
                 const double inv = 1.0 / tot;
 #pragma unroll
@@ -462,13 +498,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
             for (int q = 0; q < Q; ++q) A[q] *= b[q];
             rescale_pow2<Q>(A);
         }
-        double tot = 0.0;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const double fac = dc ? P->eta[q] * exp(-di * P->hN[q]) : P->etaF[q];
-            A[q] *= fac;
-            tot += A[q];
-        }
+        const double tot = apply_field<Q>(P, dc, di, A);
         store_vec<Q>(&sA[r * Q], A);
         const double inv = 1.0 / tot;
 #pragma unroll
@@ -564,12 +594,7 @@ k_sweep_psi_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict
         __syncthreads();
     }
     load_vec<Q>(&sAq[0], A);
-    double tot = 0.0;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        A[q] *= dc ? P->eta[q] * exp(-di * P->hN[q]) : P->etaF[q];
-        tot += A[q];
-    }
+    const double tot = apply_field<Q>(P, dc, di, A);
     const double inv = 1.0 / tot;
     if (tid == 0) {
         double pv[Q];
@@ -689,12 +714,7 @@ k_sweep_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ r
             __syncthreads();
         }
         load_vec<Q>(&sAq[0], A);  // every lane: the row product (common exponent dropped: only ratios matter)
-        double tot = 0.0;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            A[q] *= dc ? P->eta[q] * exp(-di * P->hN[q]) : P->etaF[q];
-            tot += A[q];
-        }
+        const double tot = apply_field<Q>(P, dc, di, A);
         const double inv = 1.0 / tot;
         if (tid == 0) {
             double pv[Q];
@@ -902,10 +922,7 @@ k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
                 for (int q = 0; q < Q; ++q) A[q] *= sb[e * Q + q];
                 ex += rescale_pow2<Q>(A);
             }
-            double tot = 0.0;
-#pragma unroll
-            for (int q = 0; q < Q; ++q) tot += A[q] * (dc ? P->eta[q] * exp(-di * P->hN[q]) : P->etaF[q]);
-            acc[0] += log(tot) + double(ex) * 0.6931471805599453;  // log Z_i  (bp.cpp:446-502)
+            acc[0] += log_partition<Q>(P, dc, di, A, ex);  // log Z_i  (bp.cpp:446-502)
             if (want_entropy) {  // e_site (bp.cpp:506-560): no beta, weights exp(a + log eta - h/N)
                 double C[Q];
 #pragma unroll
@@ -995,10 +1012,7 @@ k_fe_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev,
         __syncthreads();
     }
     if (tid == 0) {
-        double tot = 0.0;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) tot += A[q] * (dc ? P->eta[q] * exp(-di * P->hN[q]) : P->etaF[q]);
-        acc[0] += log(tot) + double(ex) * 0.6931471805599453;
+        acc[0] += log_partition<Q>(P, dc, di, A, ex);
         if (want_entropy) {
             double num = 0.0, den = 0.0;
 #pragma unroll

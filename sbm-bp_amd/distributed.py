@@ -94,8 +94,8 @@ class HipShardBackend:
     def sweep_partial(self, j):
         self._check(self._lib.sbmbp_shard_sweep_partial(self._h, j))
 
-    def finalize(self, mode):
-        self._check(self._lib.sbmbp_shard_finalize(self._h, mode))
+    def finalize(self, mode, n_rows):
+        self._check(self._lib.sbmbp_shard_finalize(self._h, mode, n_rows))
 
     def msgdiff_partial(self):
         self._check(self._lib.sbmbp_shard_msgdiff_partial(self._h))
@@ -160,6 +160,9 @@ class TorchDistComm:
     def all_reduce(self, tensors, op):
         self.dist.all_reduce(tensors[0], op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX)
 
+    def all_gather(self, outs, ins):
+        self.dist.all_gather_into_tensor(outs[0], ins[0])
+
 
 class LocalComm:
     """all shards live in this process (lock-step); collectives are tensor copies"""
@@ -181,6 +184,12 @@ class LocalComm:
                     s0 = int(send_off[p][r])
                     recv_views[r][off:off + n].copy_(sendbufs[p][s0:s0 + n])
                 off += n
+
+    def all_gather(self, outs, ins):
+        import torch
+        cat = torch.cat([t.to(outs[0].device) for t in ins])
+        for o in outs:
+            o.copy_(cat.to(o.device))
 
     def all_reduce(self, tensors, op):
         import torch
@@ -254,21 +263,28 @@ class ShardedBP:
         if n_max:
             self.comm.all_reduce([sh.red[n_sum:n_sum + n_max] for sh in self.shards], "max")
 
+    def _gather_red(self):
+        """every shard's red[0..Q] (Q field sums + hint) -> all shards, at red[16 + r*(Q+1)]: ONE collective
+        per sweep; k_finalize folds the rows (sum / max) in rank order, identically on every shard"""
+        n = self.Q + 1
+        w = self.comm.world
+        self.comm.all_gather([sh.red[16:16 + w * n] for sh in self.shards], [sh.red[:n] for sh in self.shards])
+
     def _queue_sweep(self, j):
         self._exchange(j)
         for sh in self.shards:
             sh.sweep_partial(j)
-        self._reduce(self.Q, 1)
+        self._gather_red()
         for sh in self.shards:
-            sh.finalize(0)
+            sh.finalize(0, self.comm.world)
 
     def _begin(self, armed):
         for sh in self.shards:
             sh.begin(armed)
             sh.field_partial(0)
-        self._reduce(self.Q, 0)
+        self._gather_red()
         for sh in self.shards:
-            sh.finalize(1)
+            sh.finalize(1, self.comm.world)
 
     def _exact_diff(self):
         for sh in self.shards:

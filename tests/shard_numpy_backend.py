@@ -62,6 +62,7 @@ class NumpyShardBackend:
     def field_partial(self, j):
         p = self.psi[self.read_buffer(j)][:self.plan.n_own].numpy()
         self.red[:self.Q] = torch.from_numpy((self._g()[:, None] * p).sum(0))
+        self.red[self.Q] = 0.0
 
     def sweep_partial(self, j):
         if self.st.stop:
@@ -92,14 +93,17 @@ class NumpyShardBackend:
         self.red[:self.Q] = torch.from_numpy((self._g()[:, None] * psi_new).sum(0))
         self.red[self.Q] = md
 
-    def finalize(self, mode):
+    def finalize(self, mode, n_rows):
         if mode == 0 and self.st.stop:
             return
-        S = self.red[:self.Q].numpy().copy()
+        rows = self.red[16:16 + n_rows * (self.Q + 1)].numpy().reshape(n_rows, self.Q + 1)
+        S = np.zeros(self.Q)
+        for r in range(n_rows):  # fixed order, as k_finalize
+            S += rows[r, :self.Q]
         h = self.cab.T @ S
         self.hN = h / self.plan.n_global
         if mode == 0:
-            md = float(self.red[self.Q])
+            md = float(rows[:, self.Q].max())
             self.st.maxdiff = md
             if md < self.armed and self.st.conv_iter < 0:
                 self.st.conv_iter, self.st.stop = self.st.sweep_idx, 1

@@ -305,3 +305,37 @@ def test_marginal_gather_and_message_gather_forms_agree(S):
     assert abs(a0[0] - a1[0]) < 1e-12 and np.abs(a0[1] - a1[1]).max() < 1e-12 and np.abs(a0[2] - a1[2]).max() < 1e-12
     assert a0[3] == a1[3] and a0[4] < 1e-12 and a1[4] < 1e-12
     assert np.abs(a0[5] - a1[5]).max() < 1e-11 and abs(a0[6] - a1[6]) < 1e-11
+
+
+def test_degree_corrected_powerlaw_graph_c4_family(S, orc):
+    """config C4 family at test size: DC-SBM with power-law propensities, Q=8, --deg_corr_flag 1; rows
+    above the segment capacity go through the hub kernels, everything is checked against the oracle"""
+    from sbm_bp_amd import synth
+    N, Q = 30000, 8
+    pairs, cab, c_eff = synth.dc_sbm_powerlaw(N, Q, 8.0, 0.1, 3)
+    g = S.Graph.from_edges(pairs, N)
+    og = orc.Graph.from_edges(pairs, N)
+    assert g.max_degree > 512 and 6.0 < c_eff < 10.0
+    tc = synth.true_conf(N, Q)
+    na = np.array(synth.group_sizes(N, Q), dtype=np.uint32)
+    bp = S.bp_conditional()
+    bp.init_messages(S.blockmodel_t(g, Q, 1), 0, None, tc, 2)
+    bp.expand_bp_params(S.bp_blockmodel_state(cab, na))
+    assert bp.stats().n_hub_rows >= 1
+    obp = orc.OracleBP(og, Q, 1)
+    obp.init_messages(0, None, tc, orc.Rng(2))
+    obp.set_params(cab, na, 1.0)
+    for _ in range(4):
+        assert abs(bp.sweep(1, 1.0) - obp.sweep_sync(1.0)) < 1e-9
+    psi, msg = bp.get_state()
+    opsi, omsg = obp.get_state()
+    # rows with ~1000 factors: products in a different order differ by ~1e-11 (north star: 1e-5)
+    assert np.abs(msg - omsg).max() < 1e-9 and np.abs(psi - opsi).max() < 1e-9
+    niter, last = bp.converge(1e-10, 2000, 1.0)
+    it2, _ = obp.converge_sync(1e-10, 2000, 1.0)
+    assert niter >= 0 and abs((niter + 4) - (it2 + 4)) <= 1
+    f, parts = bp.compute_free_energy(parts=True)
+    of, oparts = obp.free_energy(0)
+    assert np.abs(parts - oparts).max() < 1e-9 * max(1.0, np.abs(oparts).max())
+    assert abs(bp.compute_overlap() - obp.overlap()) < 1e-9
+    assert bp.compute_overlap() > 0.5  # the planted groups are recovered
