@@ -199,7 +199,9 @@ typedef struct sbmbp_shard_desc {
     const uint64_t *row_ptr;    /* host [n_own+1], local offsets */
     const uint32_t *nbr_local;  /* host [n_edges]: index into the marginal table: own < n_own <= halo */
     void *psi_buf0, *psi_buf1;  /* device, (n_own+n_halo)*Q doubles each */
-    void *red_buf;              /* device, >= 128 doubles: reduction hand-off buffer */
+    void *red_buf;              /* device, >= 8192 doubles: reduction hand-off buffer */
+    uint32_t n_chunks;          /* row chunks for overlapping the halo exchange with the sweep (0 or 1 = none) */
+    const uint32_t *chunk_row;  /* host [n_chunks+1] local row boundaries, chunk_row[0] = 0, last = n_own */
 } sbmbp_shard_desc;
 
 typedef struct sbmbp_conv_state {
@@ -221,6 +223,10 @@ int sbmbp_shard_read_buffer(sbmbp_engine_t *e, uint32_t j);
 int sbmbp_shard_field_partial(sbmbp_engine_t *e, uint32_t j);
 /* sweep j over the owned rows; red[0..Q) = partial sums of the new marginals, red[Q] = hint */
 int sbmbp_shard_sweep_partial(sbmbp_engine_t *e, uint32_t j);
+/* the same in pieces: sweep j over row chunk c only (the caller ships chunk c's new marginals while
+ * chunk c+1 runs), then one fold of all chunks' partials into red */
+int sbmbp_shard_sweep_chunk(sbmbp_engine_t *e, uint32_t j, uint32_t c);
+int sbmbp_shard_sweep_fold(sbmbp_engine_t *e);
 /* consume the reduction values: n_rows rows of (Q+1) doubles starting at red + 16 (the caller
  * all-gathers every shard's red[0..Q] there; n_rows = number of shards). Rows are folded in order —
  * sums for the Q field entries, max for the hint. mode 0 after a sweep, 1 field initialisation */

@@ -80,6 +80,8 @@ SYMBOLS = {
     "sbmbp_shard_read_buffer": (C.c_int, [C.c_void_p, C.c_uint32]),
     "sbmbp_shard_field_partial": (C.c_int, [C.c_void_p, C.c_uint32]),
     "sbmbp_shard_sweep_partial": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "sbmbp_shard_sweep_chunk": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "sbmbp_shard_sweep_fold": (C.c_int, [C.c_void_p]),
     "sbmbp_shard_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
     "sbmbp_shard_msgdiff_partial": (C.c_int, [C.c_void_p]),
     "sbmbp_shard_rowsums_partial": (C.c_int, [C.c_void_p]),

@@ -44,6 +44,7 @@ struct sbmbp_engine {
     uint32_t Nglob = 0, n_halo = 0, row0 = 0;
     uint64_t edge0 = 0;
     double *d_red = nullptr;  // caller-owned reduction hand-off buffer (shards)
+    std::vector<uint32_t> chunk_blk, chunk_hub;  // per row chunk: first segment / first hub row (n_chunks+1 entries)
     // graph + work decomposition in HBM
     uint32_t *d_row_ptr = nullptr, *d_rev = nullptr, *d_nbr = nullptr, *d_src = nullptr;
     uint32_t *d_blk_row = nullptr, *d_hub_row = nullptr, *d_hub_blk = nullptr, *d_true = nullptr;
@@ -245,12 +246,16 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form) {
 }
 
 int collect_timing(sbmbp_engine *e) {
+    size_t pieces = 0;
     for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
         e->sweep_ms += double(ms);
-        e->sweep_launches++;
+        ++pieces;
     }
+    // a chunked shard sweep is timed per chunk; the chunks of one sweep together process the shard's edges once
+    const size_t per_sweep = e->sharded ? std::max<size_t>(1, e->chunk_blk.size() - 1) : 1;
+    e->sweep_launches += pieces / per_sweep;
     e->ev_used = 0;
     return SBMBP_OK;
 }
@@ -1104,9 +1109,24 @@ int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *d, uint32_t
     e->own_stream = true;
     const uint32_t cap = uint32_t(frame_cap(Q)), rcap = uint32_t(frame_rcap(Q));
     std::vector<uint32_t> blk_row, hub_row, hub_blk, rp32(size_t(d->n_own) + 1);
+    std::vector<uint32_t> chunk_row;  // segments never straddle a chunk boundary
+    if (d->n_chunks > 1 && d->chunk_row) chunk_row.assign(d->chunk_row, d->chunk_row + d->n_chunks + 1);
+    else chunk_row = {0u, d->n_own};
+    if (chunk_row.front() != 0 || chunk_row.back() != d->n_own) { delete e; set_error("chunk_row must span [0, n_own]"); return SBMBP_ERR_ARG; }
+    for (size_t c = 1; c < chunk_row.size(); ++c)
+        if (chunk_row[c] < chunk_row[c - 1]) { delete e; set_error("chunk_row not monotone"); return SBMBP_ERR_ARG; }
     blk_row.push_back(0);
     uint32_t rows = 0, edges = 0;
+    size_t next_chunk = 1;
+    e->chunk_blk.push_back(0);
+    e->chunk_hub.push_back(0);
     for (uint32_t i = 0; i < d->n_own; ++i) {
+        while (next_chunk < chunk_row.size() - 1 && i == chunk_row[next_chunk]) {  // close the open segment at a chunk boundary
+            if (rows) { blk_row.push_back(i); rows = 0; edges = 0; }
+            e->chunk_blk.push_back(uint32_t(blk_row.size() - 1));
+            e->chunk_hub.push_back(uint32_t(hub_row.size()));
+            ++next_chunk;
+        }
         if (d->row_ptr[i + 1] < d->row_ptr[i]) { delete e; set_error("row_ptr not monotone"); return SBMBP_ERR_ARG; }
         const uint32_t dg = uint32_t(d->row_ptr[i + 1] - d->row_ptr[i]);
         if (dg > cap) {
@@ -1121,6 +1141,10 @@ int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *d, uint32_t
         edges += dg;
     }
     if (blk_row.back() != d->n_own) blk_row.push_back(d->n_own);
+    while (e->chunk_blk.size() < chunk_row.size()) {  // trailing (possibly empty) chunks and the end sentinel
+        e->chunk_blk.push_back(uint32_t(blk_row.size() - 1));
+        e->chunk_hub.push_back(uint32_t(hub_row.size()));
+    }
     for (size_t i = 0; i <= d->n_own; ++i) rp32[i] = uint32_t(d->row_ptr[i]);
     e->h_row_ptr = rp32;
     e->n_blk = uint32_t(blk_row.size() - 1);
@@ -1189,15 +1213,18 @@ int sbmbp_shard_field_partial(sbmbp_engine_t *e, uint32_t j) {
     return SBMBP_OK;
 }
 
-int sbmbp_shard_sweep_partial(sbmbp_engine_t *e, uint32_t j) {
+int sbmbp_shard_sweep_chunk(sbmbp_engine_t *e, uint32_t j, uint32_t c) {
     IS_SHARD(e);
+    if (c + 1 >= e->chunk_blk.size()) { set_error("chunk index out of range"); return SBMBP_ERR_ARG; }
     const int mc = (e->cur + int(j)) & 1, pc = (e->pcur + int(j)) & 1;
     double *Mio = e->d_M[mc ^ 1];
     const double *psi_old = e->d_psi[pc];
     double *psi_new = e->d_psi[pc ^ 1];
     CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (e->Q + 1)));
+    const uint32_t b0 = e->chunk_blk[c], nb = e->chunk_blk[c + 1] - b0;
+    const uint32_t h0 = e->chunk_hub[c], nh = e->chunk_hub[c + 1] - h0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (e->timing) {
+    if (e->timing && nb) {
         if (e->ev_used + 2 > e->ev.size()) {
             size_t old = e->ev.size();
             e->ev.resize(old + 256);
@@ -1207,13 +1234,21 @@ int sbmbp_shard_sweep_partial(sbmbp_engine_t *e, uint32_t j) {
         e1 = e->ev[e->ev_used++];
         HIPCHK(hipEventRecord(e0, e->stream));
     }
-    DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr, Mio,
-                                        psi_old, psi_new, e->d_blk_row, e->d_P, int(e->dc), e->d_partials));
-    if (e->timing) HIPCHK(hipEventRecord(e1, e->stream));
-    if (e->n_hub)
-        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi_hub<QQ>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
-                                            e->d_nbr, Mio, psi_old, psi_new, e->d_hub_row, e->d_hub_blk, e->d_P,
+    if (nb)
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ>), dim3(nb), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr, Mio,
+                                            psi_old, psi_new, e->d_blk_row + b0, e->d_P, int(e->dc),
+                                            e->d_partials + size_t(b0) * (e->Q + 1)));
+    if (e->timing && nb) HIPCHK(hipEventRecord(e1, e->stream));
+    if (nh)
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi_hub<QQ>), dim3(nh), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
+                                            e->d_nbr, Mio, psi_old, psi_new, e->d_hub_row + h0, e->d_hub_blk + h0, e->d_P,
                                             int(e->dc), e->d_partials));
+    HIPCHK(hipGetLastError());
+    return SBMBP_OK;
+}
+
+int sbmbp_shard_sweep_fold(sbmbp_engine_t *e) {
+    IS_SHARD(e);
     uint32_t rows = e->n_blk;
     const double *part = fold_stage(e, &rows, int(e->Q), 1, e->Q + 1);
     hipLaunchKernelGGL(k_fold_stage, dim3(1), dim3(BLOCK), 0, e->stream, part, rows, rows, int(e->Q), 1, e->Q + 1, e->d_red);
@@ -1221,9 +1256,15 @@ int sbmbp_shard_sweep_partial(sbmbp_engine_t *e, uint32_t j) {
     return SBMBP_OK;
 }
 
+int sbmbp_shard_sweep_partial(sbmbp_engine_t *e, uint32_t j) {
+    IS_SHARD(e);
+    for (uint32_t c = 0; c + 1 < e->chunk_blk.size(); ++c) CHK(sbmbp_shard_sweep_chunk(e, j, c));
+    return sbmbp_shard_sweep_fold(e);
+}
+
 int sbmbp_shard_finalize(sbmbp_engine_t *e, int mode, uint32_t n_rows) {
     IS_SHARD(e);
-    if ((mode != 0 && mode != 1) || n_rows == 0 || 16 + uint64_t(n_rows) * (e->Q + 1) > 128) return SBMBP_ERR_ARG;
+    if ((mode != 0 && mode != 1) || n_rows == 0 || 16 + uint64_t(n_rows) * (e->Q + 1) > 8192) return SBMBP_ERR_ARG;
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, e->stream, e->d_red + 16, n_rows, int(e->Q), mode, e->d_P, e->d_hist, e->hist_cap);
     HIPCHK(hipGetLastError());
     return SBMBP_OK;

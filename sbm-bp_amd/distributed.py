@@ -26,7 +26,7 @@ class ShardDesc(C.Structure):
     _fields_ = [("n_global", C.c_uint32), ("n_own", C.c_uint32), ("n_halo", C.c_uint32), ("row0", C.c_uint32),
                 ("n_edges", C.c_uint64), ("edge0", C.c_uint64), ("row_ptr", C.POINTER(C.c_uint64)),
                 ("nbr_local", C.POINTER(C.c_uint32)), ("psi_buf0", C.c_void_p), ("psi_buf1", C.c_void_p),
-                ("red_buf", C.c_void_p)]
+                ("red_buf", C.c_void_p), ("n_chunks", C.c_uint32), ("chunk_row", C.POINTER(C.c_uint32))]
 
 
 class ConvState(C.Structure):
@@ -45,14 +45,16 @@ class HipShardBackend:
         self.device = torch.device("cuda", device)
         n_tab = plan.n_own + plan.n_halo
         self.psi = torch.zeros((2, n_tab, Q), dtype=torch.float64, device=self.device)
-        self.red = torch.zeros(128, dtype=torch.float64, device=self.device)
-        self.send_idx = torch.as_tensor(plan.send_idx.astype(np.int32), device=self.device)
-        self.sendbuf = torch.zeros((max(1, len(plan.send_idx)), Q), dtype=torch.float64, device=self.device)
+        self.red = torch.zeros(8192, dtype=torch.float64, device=self.device)
+        self.send_idx = torch.as_tensor(plan.send_idx_chunked.astype(np.int32), device=self.device)
+        self.sendbuf = torch.zeros((max(1, len(plan.send_idx_chunked)), Q), dtype=torch.float64, device=self.device)
         self._row_ptr = np.ascontiguousarray(plan.row_ptr, dtype=np.uint64)
         self._nbr = np.ascontiguousarray(plan.nbr_local, dtype=np.uint32)
+        self._chunk_row = np.ascontiguousarray(plan.chunk_row, dtype=np.uint32)
         d = ShardDesc(plan.n_global, plan.n_own, plan.n_halo, plan.row0, plan.n_edges, plan.edge0,
                       self._row_ptr.ctypes.data_as(C.POINTER(C.c_uint64)), self._nbr.ctypes.data_as(C.POINTER(C.c_uint32)),
-                      self.psi[0].data_ptr(), self.psi[1].data_ptr(), self.red.data_ptr())
+                      self.psi[0].data_ptr(), self.psi[1].data_ptr(), self.red.data_ptr(), plan.n_chunks,
+                      self._chunk_row.ctypes.data_as(C.POINTER(C.c_uint32)))
         h = C.c_void_p()
         self._check(self._lib.sbmbp_shard_create(C.byref(h), C.byref(d), Q, dc, device))
         self._h = h
@@ -82,11 +84,19 @@ class HipShardBackend:
     def read_buffer(self, j):
         return self._lib.sbmbp_shard_read_buffer(self._h, j)
 
-    def pack(self, j):
-        n = len(self.plan.send_idx)
+    def pack(self, j, c):
+        """gather the chunk-c send rows of the table sweep j reads into their slice of sendbuf"""
+        off = int(self.plan.send_off_cp[c, 0])
+        n = int(self.plan.send_counts_cp[c].sum())
         if n:
-            self._check(self._lib.sbmbp_shard_pack(self._h, j, C.cast(self.send_idx.data_ptr(), C.POINTER(C.c_uint32)), n,
-                                                   C.cast(self.sendbuf.data_ptr(), C.POINTER(C.c_double))))
+            self._check(self._lib.sbmbp_shard_pack(self._h, j, C.cast(self.send_idx.data_ptr() + 4 * off, C.POINTER(C.c_uint32)), n,
+                                                   C.cast(self.sendbuf.data_ptr() + 8 * self.Q * off, C.POINTER(C.c_double))))
+
+    def sweep_chunk(self, j, c):
+        self._check(self._lib.sbmbp_shard_sweep_chunk(self._h, j, c))
+
+    def sweep_fold(self):
+        self._check(self._lib.sbmbp_shard_sweep_fold(self._h))
 
     def field_partial(self, j):
         self._check(self._lib.sbmbp_shard_field_partial(self._h, j))
@@ -154,8 +164,18 @@ class TorchDistComm:
     def local_ranks(self):
         return [self.rank]
 
-    def all_to_all(self, recv_views, sendbufs, recv_counts, send_counts):
-        self.dist.all_to_all_single(recv_views[0], sendbufs[0], [int(x) for x in recv_counts[0]], [int(x) for x in send_counts[0]])
+    def exchange(self, recv_lists, send_lists):
+        """recv_lists[0][p] / send_lists[0][p]: tensor views per peer (may be empty). Grouped
+        non-blocking send/recv (RCCL: one ncclGroup); returns the works to wait on."""
+        ops = []
+        for p in range(self.world):
+            if p == self.rank:
+                continue
+            if send_lists[0][p].shape[0]:
+                ops.append(self.dist.P2POp(self.dist.isend, send_lists[0][p], p))
+            if recv_lists[0][p].shape[0]:
+                ops.append(self.dist.P2POp(self.dist.irecv, recv_lists[0][p], p))
+        return self.dist.batch_isend_irecv(ops) if ops else []
 
     def all_reduce(self, tensors, op):
         self.dist.all_reduce(tensors[0], op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX)
@@ -173,17 +193,13 @@ class LocalComm:
     def local_ranks(self):
         return list(range(self.world))
 
-    def all_to_all(self, recv_views, sendbufs, recv_counts, send_counts):
-        send_off = [np.concatenate([[0], np.cumsum(sc)]) for sc in send_counts]
+    def exchange(self, recv_lists, send_lists):
         for r in range(self.world):
-            off = 0
             for p in range(self.world):
-                n = int(recv_counts[r][p])
-                if n:
-                    assert int(send_counts[p][r]) == n
-                    s0 = int(send_off[p][r])
-                    recv_views[r][off:off + n].copy_(sendbufs[p][s0:s0 + n])
-                off += n
+                if p != r and recv_lists[r][p].shape[0]:
+                    assert recv_lists[r][p].shape == send_lists[p][r].shape
+                    recv_lists[r][p].copy_(send_lists[p][r])
+        return []
 
     def all_gather(self, outs, ins):
         import torch
@@ -217,9 +233,11 @@ class ShardedBP:
 
     # -- construction -------------------------------------------------------------------------
     @classmethod
-    def from_csr(cls, row_ptr, nbr, Q, dc, comm, backend_factory=None):
+    def from_csr(cls, row_ptr, nbr, Q, dc, comm, backend_factory=None, n_chunks=None):
         bounds = partition_rows(row_ptr, comm.world)
-        plans = [ShardPlan(row_ptr, nbr, bounds, r) for r in comm.local_ranks()]
+        if n_chunks is None:
+            n_chunks = 1 if comm.world == 1 else 4
+        plans = [ShardPlan(row_ptr, nbr, bounds, r, n_chunks) for r in comm.local_ranks()]
         self = cls(plans, Q, dc, comm, backend_factory)
         self.E2_global = int(len(nbr))
         self.bounds = bounds
@@ -250,12 +268,18 @@ class ShardedBP:
             sh.set_params(cab, na, beta)
 
     # -- one sweep = exchange, local sweep, reduce, finalize ------------------------------------
-    def _exchange(self, j):
+    def _exchange_chunk(self, j, c):
+        """ship the chunk-c boundary marginals of the table that sweep j reads into the peers' halos"""
         for sh in self.shards:
-            sh.pack(j)
-        recv = [sh.psi[sh.read_buffer(j)][p.n_own:] for sh, p in zip(self.shards, self.plans)]
-        send = [sh.sendbuf[:len(p.send_idx)] for sh, p in zip(self.shards, self.plans)]
-        self.comm.all_to_all(recv, send, [p.recv_counts for p in self.plans], [p.send_counts for p in self.plans])
+            sh.pack(j, c)
+        recv, send = [], []
+        for sh, p in zip(self.shards, self.plans):
+            tab = sh.psi[sh.read_buffer(j)]
+            recv.append([tab[p.n_own + int(p.recv_off_cp[c, q]):p.n_own + int(p.recv_off_cp[c, q]) + int(p.recv_counts_cp[c, q])]
+                         for q in range(self.comm.world)])
+            send.append([sh.sendbuf[int(p.send_off_cp[c, q]):int(p.send_off_cp[c, q]) + int(p.send_counts_cp[c, q])]
+                         for q in range(self.comm.world)])
+        return self.comm.exchange(recv, send)
 
     def _reduce(self, n_sum, n_max):
         if n_sum:
@@ -271,14 +295,27 @@ class ShardedBP:
         self.comm.all_gather([sh.red[16:16 + w * n] for sh in self.shards], [sh.red[:n] for sh in self.shards])
 
     def _queue_sweep(self, j):
-        self._exchange(j)
+        """sweep j reads a table whose halo is already in place (shipped during sweep j-1 or by _begin);
+        the new marginals of chunk c travel while chunk c+1 is swept"""
+        works = []
+        for c in range(self.plans[0].n_chunks):
+            for sh in self.shards:
+                sh.sweep_chunk(j, c)
+            works += self._exchange_chunk(j + 1, c)
+        for w in works:
+            w.wait()
         for sh in self.shards:
-            sh.sweep_partial(j)
+            sh.sweep_fold()
         self._gather_red()
         for sh in self.shards:
             sh.finalize(0, self.comm.world)
 
     def _begin(self, armed):
+        works = []
+        for c in range(self.plans[0].n_chunks):  # halo of the table the first sweep reads
+            works += self._exchange_chunk(0, c)
+        for w in works:
+            w.wait()
         for sh in self.shards:
             sh.begin(armed)
             sh.field_partial(0)

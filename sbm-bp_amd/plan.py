@@ -24,10 +24,25 @@ def partition_rows(row_ptr, world):
     return np.array(bounds, dtype=np.int64)
 
 
-class ShardPlan:
-    """everything shard `rank` needs, in local indices"""
+def chunk_rows(row_ptr_local, n_chunks):
+    """local row boundaries of n_chunks chunks balanced on sum(deg + 2) (chunks may be empty for tiny shards)"""
+    rp = np.asarray(row_ptr_local, dtype=np.int64)
+    n = len(rp) - 1
+    c = np.cumsum(np.diff(rp) + 2)
+    cuts = [0]
+    for k in range(1, n_chunks):
+        b = int(np.searchsorted(c, c[-1] * k / n_chunks)) + 1 if n else 0
+        cuts.append(min(max(b, cuts[-1]), n))
+    cuts.append(n)
+    return np.array(cuts, dtype=np.int64)
 
-    def __init__(self, row_ptr, nbr, bounds, rank):
+
+class ShardPlan:
+    """everything shard `rank` needs, in local indices. With n_chunks > 1 the owned rows are cut into
+    chunks so the new marginals of chunk c can travel while chunk c+1 is being swept; because the halo
+    is sorted by global id, the entries a peer sends for one of ITS chunks are a contiguous slice."""
+
+    def __init__(self, row_ptr, nbr, bounds, rank, n_chunks=1):
         row_ptr = np.asarray(row_ptr, dtype=np.int64)
         bounds = np.asarray(bounds, dtype=np.int64)
         self.rank, self.world = int(rank), len(bounds) - 1
@@ -56,6 +71,31 @@ class ShardPlan:
         self.send_counts = np.bincount(key // max(self.n_own, 1), minlength=self.world).astype(np.int64)
         self.send_idx = (key % max(self.n_own, 1)).astype(np.int64)  # local row ids, grouped by destination
         self.deg = np.diff(self.row_ptr.astype(np.int64))
+        # ---- chunked views of the same lists
+        self.n_chunks = max(1, int(n_chunks))
+        W, Cn = self.world, self.n_chunks
+        all_chunks = [bounds[p] + chunk_rows(row_ptr[bounds[p]:bounds[p + 1] + 1] - row_ptr[bounds[p]], Cn) for p in range(W)]
+        self.chunk_row = (all_chunks[rank] - lo).astype(np.uint32)
+        send_off = np.concatenate([[0], np.cumsum(self.send_counts)])
+        self.send_counts_cp = np.zeros((Cn, W), dtype=np.int64)
+        pieces = [[None] * W for _ in range(Cn)]
+        for p in range(W):
+            rows_p = self.send_idx[send_off[p]:send_off[p + 1]]
+            cut = np.searchsorted(rows_p, self.chunk_row.astype(np.int64))
+            for c in range(Cn):
+                pieces[c][p] = rows_p[cut[c]:cut[c + 1]]
+                self.send_counts_cp[c, p] = cut[c + 1] - cut[c]
+        self.send_idx_chunked = np.concatenate([pieces[c][p] for c in range(Cn) for p in range(W)]) if self.send_idx.size else self.send_idx
+        self.send_off_cp = np.concatenate([[0], np.cumsum(self.send_counts_cp.ravel())])[:-1].reshape(Cn, W)
+        halo_off = np.concatenate([[0], np.cumsum(self.recv_counts)])
+        self.recv_counts_cp = np.zeros((Cn, W), dtype=np.int64)
+        self.recv_off_cp = np.zeros((Cn, W), dtype=np.int64)  # offsets into the halo part of the table
+        for p in range(W):
+            h = remote[halo_off[p]:halo_off[p + 1]]
+            cut = np.searchsorted(h, all_chunks[p])
+            for c in range(Cn):
+                self.recv_counts_cp[c, p] = cut[c + 1] - cut[c]
+                self.recv_off_cp[c, p] = halo_off[p] + cut[c]
 
     def summary(self):
         return dict(rank=self.rank, n_own=self.n_own, n_halo=self.n_halo, n_edges=self.n_edges,

@@ -16,8 +16,8 @@ class NumpyShardBackend:
         self.plan, self.Q, self.dc = plan, Q, dc
         n_tab = plan.n_own + plan.n_halo
         self.psi = torch.zeros((2, n_tab, Q), dtype=torch.float64)
-        self.red = torch.zeros(128, dtype=torch.float64)
-        self.sendbuf = torch.zeros((max(1, len(plan.send_idx)), Q), dtype=torch.float64)
+        self.red = torch.zeros(8192, dtype=torch.float64)
+        self.sendbuf = torch.zeros((max(1, len(plan.send_idx_chunked)), Q), dtype=torch.float64)
         self.M = [np.zeros((plan.n_edges, Q)), np.zeros((plan.n_edges, Q))]
         self.cur = self.pcur = 0
         self.st = State()
@@ -51,10 +51,11 @@ class NumpyShardBackend:
     def read_buffer(self, j):
         return (self.pcur + j) & 1
 
-    def pack(self, j):
-        n = len(self.plan.send_idx)
+    def pack(self, j, c):
+        off, n = int(self.plan.send_off_cp[c, 0]), int(self.plan.send_counts_cp[c].sum())
         if n:
-            self.sendbuf[:n] = self.psi[self.read_buffer(j)][torch.from_numpy(self.plan.send_idx)]
+            idx = torch.from_numpy(self.plan.send_idx_chunked[off:off + n])
+            self.sendbuf[off:off + n] = self.psi[self.read_buffer(j)][idx]
 
     def _g(self):
         return self.plan.deg.astype(np.float64) if self.dc else np.ones(self.plan.n_own)
@@ -64,34 +65,46 @@ class NumpyShardBackend:
         self.red[:self.Q] = torch.from_numpy((self._g()[:, None] * p).sum(0))
         self.red[self.Q] = 0.0
 
-    def sweep_partial(self, j):
+    def sweep_chunk(self, j, c):
         if self.st.stop:
             return
         pl = self.plan
-        Mio = self.M[((self.cur + j) & 1) ^ 1]
+        if c == 0:
+            self._S, self._md = np.zeros(self.Q), 0.0
+        r0, r1 = int(pl.chunk_row[c]), int(pl.chunk_row[c + 1])
+        e0, e1 = int(pl.row_ptr[r0]), int(pl.row_ptr[r1])
+        Mio = self.M[((self.cur + j) & 1) ^ 1][e0:e1]
         pold = self.psi[(self.pcur + j) & 1].numpy()
         pnew = self.psi[((self.pcur + j) & 1) ^ 1].numpy()
+        src = self.src[e0:e1] - r0
+        deg = pl.deg[r0:r1]
         bo = Mio @ self.W
-        inc = pold[pl.nbr_local.astype(np.int64)] / bo
+        inc = pold[pl.nbr_local[e0:e1].astype(np.int64)] / bo
         inc /= inc.sum(1, keepdims=True)
         logb = np.log(inc @ self.W)
-        logA = np.zeros((pl.n_own, self.Q))
-        np.add.at(logA, self.src, logb)
+        logA = np.zeros((r1 - r0, self.Q))
+        np.add.at(logA, src, logb)
         if self.dc == 0:
-            fac = np.log(self.eta) - self.beta * self.hN
-            logA += fac[None, :]
+            logA += (np.log(self.eta) - self.beta * self.hN)[None, :]
         else:
-            logA += np.log(self.eta)[None, :] - pl.deg[:, None] * self.hN[None, :]
-        A = np.exp(logA - logA.max(1, keepdims=True))
-        psi_new = A / A.sum(1, keepdims=True)
-        cav = logA[self.src] - logb
-        cav = np.exp(cav - cav.max(1, keepdims=True))
-        new = cav / cav.sum(1, keepdims=True)
-        md = float(np.abs(new - Mio).max()) if len(new) else 0.0
+            logA += np.log(self.eta)[None, :] - deg[:, None] * self.hN[None, :]
+        A = np.exp(logA - logA.max(1, keepdims=True)) if r1 > r0 else logA
+        psi_new = A / A.sum(1, keepdims=True) if r1 > r0 else A
+        cav = logA[src] - logb
+        cav = np.exp(cav - cav.max(1, keepdims=True)) if e1 > e0 else cav
+        new = cav / cav.sum(1, keepdims=True) if e1 > e0 else cav
+        if e1 > e0:
+            self._md = max(self._md, float(np.abs(new - Mio).max()))
         Mio[:] = new
-        pnew[:pl.n_own] = psi_new
-        self.red[:self.Q] = torch.from_numpy((self._g()[:, None] * psi_new).sum(0))
-        self.red[self.Q] = md
+        pnew[r0:r1] = psi_new
+        g = deg.astype(np.float64) if self.dc else np.ones(r1 - r0)
+        self._S += (g[:, None] * psi_new).sum(0)
+
+    def sweep_fold(self):
+        if self.st.stop:
+            return
+        self.red[:self.Q] = torch.from_numpy(self._S)
+        self.red[self.Q] = self._md
 
     def finalize(self, mode, n_rows):
         if mode == 0 and self.st.stop:

@@ -39,8 +39,18 @@ def test_partition_and_plan_invariants(orc):
     for world in (1, 2, 3, 8):
         bounds = partition_rows(g.row_ptr, world)
         assert bounds[0] == 0 and bounds[-1] == g.N and (np.diff(bounds) > 0).all()
-        plans = [ShardPlan(g.row_ptr, g.nbr, bounds, k) for k in range(world)]
+        plans = [ShardPlan(g.row_ptr, g.nbr, bounds, k, n_chunks=3) for k in range(world)]
         assert sum(p.n_own for p in plans) == g.N and sum(p.n_edges for p in plans) == g.E2
+        for p in plans:  # chunked exchange: per (chunk, peer) what p sends is what the peer expects, slice for slice
+            assert p.chunk_row[0] == 0 and p.chunk_row[-1] == p.n_own and (np.diff(p.chunk_row.astype(np.int64)) >= 0).all()
+            assert sorted(p.send_idx_chunked.tolist()) == sorted(p.send_idx.tolist())
+            for q in plans:
+                for c in range(3):
+                    s0, n = int(p.send_off_cp[c, q.rank]), int(p.send_counts_cp[c, q.rank])
+                    sent = p.row0 + p.send_idx_chunked[s0:s0 + n]
+                    assert ((p.row0 + p.chunk_row[c] <= sent) & (sent < p.row0 + p.chunk_row[c + 1])).all()
+                    h0, m = int(q.recv_off_cp[c, p.rank]), int(q.recv_counts_cp[c, p.rank])
+                    assert m == n and (sent == q.halo_global[h0:h0 + m]).all()
         w = [p.n_edges + 2 * p.n_own for p in plans]
         assert max(w) <= 1.2 * (sum(w) / world) + 64
         for p in plans:
