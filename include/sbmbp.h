@@ -235,6 +235,18 @@ int sbmbp_shard_finalize(sbmbp_engine_t *e, int mode, uint32_t n_rows);
 int sbmbp_shard_msgdiff_partial(sbmbp_engine_t *e);
 /* red[0..2Q+Q*Q) = na_expect, nna_expect, confusion sums over the owned rows (current marginals) */
 int sbmbp_shard_rowsums_partial(sbmbp_engine_t *e);
+/* Reductions at compute_* time (belief_propagation.cpp:744-758, 428-440, 892-989) on shards: each
+ * *_partial leaves this shard's sums in red, the caller all-reduces (SUM) the stated number of doubles,
+ * *_finish turns them into the reference's quantities on the host. Incoming messages are first
+ * materialised from the marginal table (whose halo must be current) and the previous own messages.
+ * The non-edge term uses the moment series (the exact all-pairs kernel would need every marginal). */
+int sbmbp_shard_fe_partial(sbmbp_engine_t *e, int want_entropy);                 /* all-reduce red[0..5) */
+int sbmbp_shard_fe_finish(sbmbp_engine_t *e, double *out /* f_site, f_edge, e_site, e_edge */);
+int sbmbp_shard_nonedge_partial(sbmbp_engine_t *e, int want_entropy, uint32_t *n_values, int *order);
+int sbmbp_shard_nonedge_finish(sbmbp_engine_t *e, int want_entropy, int order, double *out /* f_nonedge, e_nonedge */);
+int sbmbp_shard_em_partial(sbmbp_engine_t *e, uint32_t *n_values);
+int sbmbp_shard_em_finish(sbmbp_engine_t *e, double *na_expect, double *nna_expect, double *cab_expect);
+
 /* wait for the stream and read the convergence state */
 int sbmbp_shard_poll(sbmbp_engine_t *e, sbmbp_conv_state *out);
 /* after a poll: `executed` sweeps of the queued batch really ran; flips the buffer parities */

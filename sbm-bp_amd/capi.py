@@ -85,6 +85,12 @@ SYMBOLS = {
     "sbmbp_shard_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
     "sbmbp_shard_msgdiff_partial": (C.c_int, [C.c_void_p]),
     "sbmbp_shard_rowsums_partial": (C.c_int, [C.c_void_p]),
+    "sbmbp_shard_fe_partial": (C.c_int, [C.c_void_p, C.c_int]),
+    "sbmbp_shard_fe_finish": (C.c_int, [C.c_void_p, c_dp]),
+    "sbmbp_shard_nonedge_partial": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    "sbmbp_shard_nonedge_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dp]),
+    "sbmbp_shard_em_partial": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "sbmbp_shard_em_finish": (C.c_int, [C.c_void_p, c_dp, c_dp, c_dp]),
     "sbmbp_shard_poll": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sbmbp_shard_commit": (C.c_int, [C.c_void_p, C.c_uint32]),
     "sbmbp_shard_rearm": (C.c_int, [C.c_void_p, C.c_double]),

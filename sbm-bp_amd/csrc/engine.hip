@@ -44,6 +44,7 @@ struct sbmbp_engine {
     uint32_t Nglob = 0, n_halo = 0, row0 = 0;
     uint64_t edge0 = 0;
     double *d_red = nullptr;  // caller-owned reduction hand-off buffer (shards)
+    double *d_Min = nullptr;  // shards: materialised incoming messages for the reductions (allocated on first use)
     std::vector<uint32_t> chunk_blk, chunk_hub;  // per row chunk: first segment / first hub row (n_chunks+1 entries)
     // graph + work decomposition in HBM
     uint32_t *d_row_ptr = nullptr, *d_rev = nullptr, *d_nbr = nullptr, *d_src = nullptr;
@@ -380,6 +381,14 @@ int fold_to_host(sbmbp_engine *e, uint32_t rows, uint32_t cols, uint32_t stride,
     return SBMBP_OK;
 }
 
+// same fold, result left in device memory (no host sync): shard steps hand it to a collective
+int fold_to_device(sbmbp_engine *e, uint32_t rows, uint32_t cols, uint32_t stride, double *d_out) {
+    const double *part = fold_stage(e, &rows, int(cols), 0, stride);
+    hipLaunchKernelGGL(k_fold_rows_sum, dim3(1), dim3(BLOCK), 0, e->stream, part, rows, cols, stride, d_out);
+    HIPCHK(hipGetLastError());
+    return SBMBP_OK;
+}
+
 int refresh_field(sbmbp_engine *e) {
     if (!e->have_params || !e->have_state) { set_error("engine has no parameters or no state"); return SBMBP_ERR_STATE; }
     CHK(launch_field(e, 2));
@@ -387,26 +396,28 @@ int refresh_field(sbmbp_engine *e) {
     return SBMBP_OK;
 }
 
-int site_edge_terms(sbmbp_engine *e, bool want_entropy, double out[4]) {
+int site_edge_terms(sbmbp_engine *e, bool want_entropy, double out[4], double *d_out = nullptr) {
     CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (FE_NP + 1)));
     const double *M = e->d_M[e->cur];
+    const double *Min = e->sharded ? e->d_Min : nullptr;
     if (e->dc == 2) {
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_frame<QQ, true>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
-                                            e->d_rev, e->d_nbr, M, e->d_blk_row, e->d_P, 1, int(want_entropy), e->d_partials));
+                                            e->d_rev, e->d_nbr, M, Min, e->d_blk_row, e->d_P, 1, int(want_entropy), e->d_partials));
         if (e->n_hub)
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
-                                                e->d_rev, e->d_nbr, M, e->d_hub_row, e->d_hub_blk, e->d_P, 1,
+                                                e->d_rev, e->d_nbr, M, Min, e->d_hub_row, e->d_hub_blk, e->d_P, 1,
                                                 int(want_entropy), e->d_partials));
     } else {
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_frame<QQ, false>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
-                                            e->d_rev, e->d_nbr, M, e->d_blk_row, e->d_P, int(e->dc), int(want_entropy),
+                                            e->d_rev, e->d_nbr, M, Min, e->d_blk_row, e->d_P, int(e->dc), int(want_entropy),
                                             e->d_partials));
         if (e->n_hub)
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_hub<QQ, false>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
-                                                e->d_rev, e->d_nbr, M, e->d_hub_row, e->d_hub_blk, e->d_P, int(e->dc),
+                                                e->d_rev, e->d_nbr, M, Min, e->d_hub_row, e->d_hub_blk, e->d_P, int(e->dc),
                                                 int(want_entropy), e->d_partials));
     }
     HIPCHK(hipGetLastError());
+    if (d_out) return fold_to_device(e, e->n_blk, FE_NP, FE_NP + 1, d_out);
     return fold_to_host(e, e->n_blk, FE_NP, FE_NP + 1, out);
 }
 
@@ -545,12 +556,13 @@ int em_expect(sbmbp_engine *e, double *na_e, double *nna_e, double *cab_e) {
     // k_em_edges reads cab/invN from the parameter block, which is in sync with the host mirror here:
     // sbmbp_set_params uploads, and inside learning the preceding converge uploaded.
     const double *M = e->d_M[e->cur];
+    const double *Min = e->sharded ? e->d_Min : nullptr;
     if (e->dc == 2) {
         DISPATCH_Q(Q, hipLaunchKernelGGL((k_em_edges<QQ, true>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_rev,
-                                         e->d_nbr, e->d_src, M, uint32_t(e->E2), e->d_P, e->d_partials));
+                                         e->d_nbr, e->d_src, M, Min, uint32_t(e->E2), e->d_P, e->d_partials));
     } else {
         DISPATCH_Q(Q, hipLaunchKernelGGL((k_em_edges<QQ, false>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_rev,
-                                         e->d_nbr, e->d_src, M, uint32_t(e->E2), e->d_P, e->d_partials));
+                                         e->d_nbr, e->d_src, M, Min, uint32_t(e->E2), e->d_P, e->d_partials));
     }
     HIPCHK(hipGetLastError());
     std::vector<double> tri(T);
@@ -824,7 +836,7 @@ void sbmbp_destroy(sbmbp_engine_t *e) {
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->ext_psi) e->d_psi[0] = e->d_psi[1] = nullptr;  // caller-owned
     void *ptrs[] = {e->d_row_ptr, e->d_rev, e->d_nbr, e->d_src, e->d_blk_row, e->d_hub_row, e->d_hub_blk, e->d_true,
-                    e->d_clamp, e->d_M[0], e->d_M[1], e->d_psi[0], e->d_psi[1], e->d_P, e->d_partials, e->d_small, e->d_hist, e->d_mats,
+                    e->d_clamp, e->d_M[0], e->d_M[1], e->d_psi[0], e->d_psi[1], e->d_Min, e->d_P, e->d_partials, e->d_small, e->d_hist, e->d_mats,
                     e->d_stage};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto ev : e->ev) hipEventDestroy(ev);
@@ -1328,6 +1340,183 @@ int sbmbp_shard_rearm(sbmbp_engine_t *e, double armed_crit) {
                           hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(e->d_P) + offsetof(dev_params, crit), &armed_crit, 8, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    return SBMBP_OK;
+}
+
+}  // extern "C"
+
+// ---- reductions on shards: partial -> (caller all-reduces red) -> finish ----------------------------
+static int shard_materialize(sbmbp_engine_t *e) {
+    if (!e->d_Min) CHK(dev_alloc(e, &e->d_Min, e->E2 * e->Q));
+    if (e->E2 == 0) return SBMBP_OK;
+    const uint32_t nb = uint32_t(std::min<uint64_t>(4096, (e->E2 + BLOCK - 1) / BLOCK));
+    DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_materialize_in<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_nbr, e->d_M[e->cur ^ 1],
+                                        e->d_psi[e->pcur], uint32_t(e->E2), e->d_P, e->d_Min));
+    HIPCHK(hipGetLastError());
+    return SBMBP_OK;
+}
+
+static void shard_nonedge_mats(const sbmbp_engine_t *e, std::vector<double> &mats, double &wmax) {
+    const uint32_t Q = e->Q;
+    mats.assign(3 * Q * Q, 0.0);
+    wmax = 0.0;
+    for (uint32_t a = 0; a < Q * Q; ++a) {
+        const double Pm = std::pow(1.0 - e->cab[a] / double(e->Nglob), e->beta);
+        mats[a] = double(e->Nglob) * (1.0 - Pm);  // w
+        mats[Q * Q + a] = Pm;
+        mats[2 * Q * Q + a] = e->cab[a];
+        wmax = std::max(wmax, std::max(mats[a], e->cab[a]));
+    }
+}
+
+static int shard_series_order(const sbmbp_engine_t *e, double wmax) {
+    if (e->series_order > 0) return std::min(e->series_order, 4);
+    for (int K = 1; K <= 4; ++K)
+        if (double(e->Nglob) * std::pow(wmax / double(e->Nglob), K + 1) / (2.0 * (K + 1)) < 1e-12) return K;
+    return 4;
+}
+
+extern "C" {
+
+// red[0..4) = {sum log Z_i, sum log norm_L, e_site sum, e_edge sum} over owned rows/edges; red[4] = sum 2 d log d
+int sbmbp_shard_fe_partial(sbmbp_engine_t *e, int want_entropy) {
+    IS_SHARD(e);
+    CHK(shard_materialize(e));
+    double dummy[4];
+    CHK(site_edge_terms(e, want_entropy != 0, dummy, e->d_red));
+    double c = 0.0;
+    if (e->dc == 1)
+        for (uint32_t i = 0; i < e->N; ++i) { const double d = double(e->h_row_ptr[i + 1] - e->h_row_ptr[i]); if (d > 0) c += 2.0 * d * std::log(d); }
+    HIPCHK(hipMemcpyAsync(e->d_red + 4, &c, 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));  // c is a stack object
+    return SBMBP_OK;
+}
+
+// out = {f_site, f_edge, e_site, e_edge} from the all-reduced red[0..5)
+int sbmbp_shard_fe_finish(sbmbp_engine_t *e, double *out) {
+    IS_SHARD(e);
+    double r[5];
+    HIPCHK(hipMemcpyAsync(r, e->d_red, sizeof r, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const double N = double(e->Nglob);
+    out[0] = r[0] / N;
+    out[1] = r[1] / (2.0 * N);
+    if (e->dc == 1) { out[0] += r[4] / N; out[1] += r[4] / (2.0 * N); }
+    out[2] = r[2] / N;
+    out[3] = r[3] / (2.0 * N);
+    return SBMBP_OK;
+}
+
+// moment tensors of the owned rows (orders 1..K packed) at red[0..T), adjacent-pair sums at red[T], red[T+1];
+// returns the number of doubles to all-reduce (T + 2) in *n_values and the order used in *order
+int sbmbp_shard_nonedge_partial(sbmbp_engine_t *e, int want_entropy, uint32_t *n_values, int *order) {
+    IS_SHARD(e);
+    if (!n_values || !order) return SBMBP_ERR_ARG;
+    const uint32_t Q = e->Q;
+    if (e->dc != 0) { *n_values = 0; *order = 0; return SBMBP_OK; }
+    std::vector<double> mats;
+    double wmax;
+    shard_nonedge_mats(e, mats, wmax);
+    const int K = shard_series_order(e, wmax);
+    int T = 0, sz = 1;
+    for (int k = 1; k <= K; ++k) { sz *= int(Q); T += sz; }
+    if (uint32_t(T) + 2 > 8192) { set_error("moment tensors do not fit the reduction buffer"); return SBMBP_ERR_UNSUPPORTED; }
+    if (!e->d_mats) CHK(dev_alloc(e, &e->d_mats, 3 * Q * Q));
+    HIPCHK(hipMemcpyAsync(e->d_mats, mats.data(), mats.size() * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const uint32_t rows_per_blk = 8192;
+    const uint32_t nb = std::max<uint32_t>(1, (e->N + rows_per_blk - 1) / rows_per_blk);
+    CHK(ensure_partials(e, size_t(nb) * T));
+    hipLaunchKernelGGL(k_moments, dim3(nb), dim3(BLOCK), 0, e->stream, e->d_psi[e->pcur], e->N, int(Q), K, rows_per_blk, T, e->d_partials);
+    hipLaunchKernelGGL(k_fold_columns, dim3((T + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_partials, nb, uint32_t(T), e->d_red);
+    HIPCHK(hipGetLastError());
+    CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (NE_NP + 1)));
+    DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_adj<QQ>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
+                                     e->d_psi[e->pcur], e->d_mats, e->d_mats + 2 * Q * Q, e->d_blk_row, 1.0 / double(e->Nglob),
+                                     want_entropy, e->d_partials));
+    HIPCHK(hipGetLastError());
+    CHK(fold_to_device(e, e->n_blk, NE_NP, NE_NP + 1, e->d_red + T));
+    *n_values = uint32_t(T) + 2;
+    *order = K;
+    return SBMBP_OK;
+}
+
+// out = {f_nonedge, e_nonedge} from the all-reduced moments and adjacent sums
+int sbmbp_shard_nonedge_finish(sbmbp_engine_t *e, int want_entropy, int order, double *out) {
+    IS_SHARD(e);
+    out[0] = out[1] = 0.0;
+    if (e->dc != 0 || order <= 0) return SBMBP_OK;
+    const uint32_t Q = e->Q;
+    int T = 0, sz = 1;
+    for (int k = 1; k <= order; ++k) { sz *= int(Q); T += sz; }
+    std::vector<double> r(T + 2);
+    HIPCHK(hipMemcpyAsync(r.data(), e->d_red, r.size() * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    std::vector<double> mats;
+    double wmax;
+    shard_nonedge_mats(e, mats, wmax);
+    const double *wmat = mats.data(), *cabm = mats.data() + 2 * Q * Q;
+    std::vector<double> vmat(Q * Q);
+    for (uint32_t a = 0; a < Q * Q; ++a) vmat[a] = cabm[a] * std::log(cabm[a]);
+    const double N = double(e->Nglob);
+    double all0 = 0.0, all1 = 0.0, Nk = 1.0;
+    size_t off = 0, tsz = 1;
+    for (int k = 1; k <= order; ++k) {
+        tsz *= Q;
+        Nk *= N;
+        std::vector<const double *> ms(k, wmat);
+        all0 -= contract(r.data() + off, Q, unsigned(k), ms) / (double(k) * Nk);
+        if (want_entropy) {
+            std::vector<const double *> me(k, cabm);
+            me[0] = vmat.data();
+            all1 += contract(r.data() + off, Q, unsigned(k), me) / Nk;
+        }
+        off += tsz;
+    }
+    out[0] = (all0 - r[T]) / (2.0 * N);
+    out[1] = (all1 - r[T + 1]) / (2.0 * N);
+    return SBMBP_OK;
+}
+
+// red[0..2Q+Q*Q) row sums (na, nna, confusion), then the Q(Q+1)/2 EM numerators; *n_values doubles to all-reduce
+int sbmbp_shard_em_partial(sbmbp_engine_t *e, uint32_t *n_values) {
+    IS_SHARD(e);
+    if (!n_values) return SBMBP_ERR_ARG;
+    const uint32_t Q = e->Q, R = 2 * Q + Q * Q, T = Q * (Q + 1) / 2;
+    CHK(shard_materialize(e));
+    CHK(sbmbp_shard_rowsums_partial(e));
+    const uint32_t nb = uint32_t(std::min<uint64_t>(2048, std::max<uint64_t>(1, (e->E2 + BLOCK - 1) / BLOCK)));
+    CHK(ensure_partials(e, size_t(nb) * (T + 1)));
+    DISPATCH_Q(Q, hipLaunchKernelGGL((k_em_edges<QQ, false>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_rev, e->d_nbr,
+                                     e->d_src, e->d_M[e->cur], e->d_Min, uint32_t(e->E2), e->d_P, e->d_partials));
+    HIPCHK(hipGetLastError());
+    CHK(fold_to_device(e, nb, T, T + 1, e->d_red + R));
+    *n_values = R + T;
+    return SBMBP_OK;
+}
+
+int sbmbp_shard_em_finish(sbmbp_engine_t *e, double *na_e, double *nna_e, double *cab_e) {
+    IS_SHARD(e);
+    const uint32_t Q = e->Q, R = 2 * Q + Q * Q, T = Q * (Q + 1) / 2;
+    std::vector<double> r(R + T);
+    HIPCHK(hipMemcpyAsync(r.data(), e->d_red, r.size() * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const double *na = r.data(), *nna = r.data() + Q, *tri = r.data() + R;
+    std::vector<double> ce(Q * Q, 0.0);
+    uint32_t t = 0;
+    for (uint32_t q1 = 0; q1 < Q; ++q1)
+        for (uint32_t q2 = q1; q2 < Q; ++q2, ++t) { ce[q1 * Q + q2] = tri[t]; ce[q2 * Q + q1] = tri[t]; }
+    const double EPS = 1.0e-50;  // rescaling of belief_propagation.cpp:967-988
+    const double *nn = (e->dc == 0) ? na : nna;
+    for (uint32_t q1 = 0; q1 < Q; ++q1)
+        for (uint32_t q2 = q1; q2 < Q; ++q2)
+            if (na[q1] > EPS && na[q2] > EPS) {
+                if (q1 != q2) { ce[q1 * Q + q2] *= double(e->Nglob) / (nn[q1] * nn[q2]); ce[q2 * Q + q1] = ce[q1 * Q + q2]; }
+                else ce[q1 * Q + q2] *= 2. * double(e->Nglob) / (nn[q1] * nn[q2]);
+            }
+    if (na_e) std::copy(na, na + Q, na_e);
+    if (nna_e) std::copy(nna, nna + Q, nna_e);
+    if (cab_e) std::copy(ce.begin(), ce.end(), cab_e);
     return SBMBP_OK;
 }
 

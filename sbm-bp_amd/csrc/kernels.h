@@ -857,7 +857,8 @@ __device__ __forceinline__ void edge_terms(const dev_params *__restrict__ P, con
 template <int Q, bool DC2>
 __global__ void __launch_bounds__(FTPB)
 k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr,
-           const double *__restrict__ M, const uint32_t *__restrict__ blk_row, const dev_params *__restrict__ P,
+           const double *__restrict__ M, const double *__restrict__ Min /* incoming messages in edge order, or null: gather M[rev] */,
+           const uint32_t *__restrict__ blk_row, const dev_params *__restrict__ P,
            int dc, int want_entropy, double *__restrict__ partials) {
     constexpr int EPT = frame_cfg<Q>::EPT, CAP = frame_cfg<Q>::CAP, RCAP = frame_cfg<Q>::RCAP;
     __shared__ double sb[CAP * Q];
@@ -882,7 +883,7 @@ k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
             const int le = j * FTPB + tid;
             if (le < ne) {
                 double mi[Q], mo[Q], b[Q];
-                load_vec<Q>(M + size_t(rev[e0 + le]) * Q, mi);
+                load_vec<Q>(Min ? Min + size_t(e0 + le) * Q : M + size_t(rev[e0 + le]) * Q, mi);
                 load_vec<Q>(M + size_t(e0 + le) * Q, mo);
                 double didl = 0.0;
                 if (DC2) {
@@ -949,8 +950,9 @@ k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
 template <int Q, bool DC2>
 __global__ void __launch_bounds__(BLOCK)
 k_fe_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr,
-         const double *__restrict__ M, const uint32_t *__restrict__ hub_row, const uint32_t *__restrict__ hub_blk,
-         const dev_params *__restrict__ P, int dc, int want_entropy, double *__restrict__ partials) {
+         const double *__restrict__ M, const double *__restrict__ Min, const uint32_t *__restrict__ hub_row,
+         const uint32_t *__restrict__ hub_blk, const dev_params *__restrict__ P, int dc, int want_entropy,
+         double *__restrict__ partials) {
     __shared__ double sAq[BLOCK * Q];
     __shared__ double sCq[BLOCK * Q];
     __shared__ int sex[BLOCK];
@@ -966,7 +968,7 @@ k_fe_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev,
     for (int q = 0; q < Q; ++q) { A[q] = 1.0; C[q] = 1.0; }
     for (uint32_t le = tid; le < d; le += BLOCK) {
         double mi[Q], mo[Q], b[Q];
-        load_vec<Q>(M + size_t(rev[e0 + le]) * Q, mi);
+        load_vec<Q>(Min ? Min + size_t(e0 + le) * Q : M + size_t(rev[e0 + le]) * Q, mi);
         load_vec<Q>(M + size_t(e0 + le) * Q, mo);
         double didl = 0.0;
         if (DC2) { const uint32_t l = nbr[e0 + le]; didl = di * double(row_ptr[l + 1] - row_ptr[l]); }
@@ -1275,7 +1277,8 @@ template <int Q, bool DC2>
 __global__ void __launch_bounds__(BLOCK)
 k_em_edges(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr,
            const uint32_t *__restrict__ src /* row of each edge, DC2 only */, const double *__restrict__ M,
-           uint32_t n_edges, const dev_params *__restrict__ P, double *__restrict__ partials /* [grid][Q*Q] */) {
+           const double *__restrict__ Min, uint32_t n_edges, const dev_params *__restrict__ P,
+           double *__restrict__ partials /* [grid][Q*Q] */) {
     constexpr int T = Q * (Q + 1) / 2;
     __shared__ double sred[4 * (T + 1)];
     double acc[T];
@@ -1283,7 +1286,7 @@ k_em_edges(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
     for (int t = 0; t < T; ++t) acc[t] = 0.0;
     for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < n_edges; k += gridDim.x * BLOCK) {
         double mi[Q], mo[Q];
-        load_vec<Q>(M + size_t(rev[k]) * Q, mi);
+        load_vec<Q>(Min ? Min + size_t(k) * Q : M + size_t(rev[k]) * Q, mi);
         load_vec<Q>(M + size_t(k) * Q, mo);
         double didl = 0.0;
         if (DC2) {
@@ -1308,6 +1311,28 @@ k_em_edges(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
         for (int u = 0; u < T; ++u) acc[u] += term[u] * inv;
     }
     block_reduce_store<T>(acc, 0.0, sred, partials + size_t(blockIdx.x) * (T + 1));
+}
+
+// incoming messages in edge order, reconstructed from the marginal table and the own messages of the
+// previous sweep (same identity as k_sweep_psi): Min[k] = N( psi[nbr[k]] / (W^T Mprev[k]) ). Used by the
+// reductions of sharded engines, which hold no reverse-edge index across shards.
+template <int Q>
+__global__ void __launch_bounds__(BLOCK)
+k_materialize_in(const uint32_t *__restrict__ nbr, const double *__restrict__ Mprev, const double *__restrict__ psi,
+                 uint32_t n_edges, const dev_params *__restrict__ P, double *__restrict__ Min) {
+    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < n_edges; k += gridDim.x * BLOCK) {
+        double pl[Q], mo[Q], bo[Q], inc[Q];
+        load_vec<Q>(psi + size_t(nbr[k]) * Q, pl);
+        load_vec<Q>(Mprev + size_t(k) * Q, mo);
+        edge_field<Q, false>(P, mo, 0.0, bo);
+        double tot = 0.0;
+#pragma unroll
+        for (int s = 0; s < Q; ++s) { inc[s] = pl[s] / bo[s]; tot += inc[s]; }
+        const double inv = 1.0 / tot;
+#pragma unroll
+        for (int s = 0; s < Q; ++s) inc[s] *= inv;
+        store_vec<Q>(Min + size_t(k) * Q, inc);
+    }
 }
 
 // K5b/K6: per-row sums: na_expect, nna_expect (belief_propagation.cpp:428-440) and the confusion

@@ -113,6 +113,36 @@ class HipShardBackend:
     def rowsums_partial(self):
         self._check(self._lib.sbmbp_shard_rowsums_partial(self._h))
 
+    def fe_partial(self, want_entropy):
+        self._check(self._lib.sbmbp_shard_fe_partial(self._h, int(want_entropy)))
+
+    def fe_finish(self):
+        out = np.zeros(4)
+        self._check(self._lib.sbmbp_shard_fe_finish(self._h, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def nonedge_partial(self, want_entropy):
+        n, k = C.c_uint32(0), C.c_int(0)
+        self._check(self._lib.sbmbp_shard_nonedge_partial(self._h, int(want_entropy), C.byref(n), C.byref(k)))
+        return n.value, k.value
+
+    def nonedge_finish(self, want_entropy, order):
+        out = np.zeros(2)
+        self._check(self._lib.sbmbp_shard_nonedge_finish(self._h, int(want_entropy), order, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def em_partial(self):
+        n = C.c_uint32(0)
+        self._check(self._lib.sbmbp_shard_em_partial(self._h, C.byref(n)))
+        return n.value
+
+    def em_finish(self):
+        Q = self.Q
+        na, nna, cab = np.zeros(Q), np.zeros(Q), np.zeros((Q, Q))
+        dp = C.POINTER(C.c_double)
+        self._check(self._lib.sbmbp_shard_em_finish(self._h, na.ctypes.data_as(dp), nna.ctypes.data_as(dp), cab.ctypes.data_as(dp)))
+        return na, nna, cab
+
     def poll(self):
         st = ConvState()
         self._check(self._lib.sbmbp_shard_poll(self._h, C.byref(st)))
@@ -399,6 +429,63 @@ class ShardedBP:
 
     def na_expect(self):
         return self._row_sums()[:self.Q]
+
+    # -- reductions that need messages: free energy, entropy, EM expectations -------------------------
+    def _refresh(self):
+        """halo of the current marginal table and the exact global field (h from the current marginals)"""
+        works = []
+        for c in range(self.plans[0].n_chunks):
+            works += self._exchange_chunk(0, c)
+        for w in works:
+            w.wait()
+        for sh in self.shards:
+            sh.field_partial(0)
+        self._gather_red()
+        for sh in self.shards:
+            sh.finalize(1, self.comm.world)
+
+    def _free_energy_and_entropy(self, want_entropy):
+        self._refresh()
+        for sh in self.shards:
+            sh.fe_partial(want_entropy)
+        self._reduce(5, 0)
+        fe = [sh.fe_finish() for sh in self.shards][0]
+        nk = [sh.nonedge_partial(want_entropy) for sh in self.shards]
+        n, order = nk[0]
+        if n:
+            self._reduce(n, 0)
+        ne = [sh.nonedge_finish(want_entropy, order) for sh in self.shards][0]
+        return fe, ne
+
+    def compute_free_energy(self, parts=False):
+        """compute_free_energy (belief_propagation.cpp:744-750) over all shards"""
+        fe, ne = self._free_energy_and_entropy(False)
+        p = np.array([fe[0], fe[1], ne[0]])
+        f = -p[0] + p[1] + p[2]
+        return (f, p) if parts else f
+
+    def compute_entropy(self, parts=False):
+        """compute_entropy (belief_propagation.cpp:752-758); NaN for deg_corr_flag != 0 as the reference"""
+        if self.dc != 0:
+            nan = float("nan")
+            return (nan, np.array([nan, nan, 0.0])) if parts else nan
+        fe, ne = self._free_energy_and_entropy(True)
+        p = np.array([fe[2], fe[3], ne[1]])
+        e = -p[0] + p[1] - p[2]
+        return (e, p) if parts else e
+
+    def em_expectations(self):
+        """compute_na_expect + compute_cab_expect (belief_propagation.cpp:428-440, 892-989)"""
+        self._refresh()
+        n = [sh.em_partial() for sh in self.shards][0]
+        self._reduce(n, 0)
+        return [sh.em_finish() for sh in self.shards][0]
+
+    def inference(self, conv_crit, time_conv, dumping_rate=1.0):
+        """belief_propagation::inference (belief_propagation.cpp:77-99)"""
+        niter, last = self.converge(conv_crit, time_conv, dumping_rate)
+        return dict(niter=niter, last_maxdiff=last, free_energy=self.compute_free_energy(), entropy=self.compute_entropy(),
+                    overlap=self.compute_overlap())
 
     def local_state(self):
         return [sh.get_state() for sh in self.shards]

@@ -114,3 +114,39 @@ def test_hub_rows_both_forms_and_oracle(S, orc, Q, dc):
         assert np.abs(np.array(d) - np.array(od)).max() < 1e-11
         assert np.abs(psi - opsi).max() < 1e-11 and np.abs(msg - omsg).max() < 1e-11
         assert np.abs(parts - oparts).max() < 1e-9 * max(1.0, np.abs(oparts).max())
+
+
+@pytest.mark.parametrize("name,world", [("c1_matched_tight_seed0", 3), ("q4_tight_seed0", 2), ("c1_dc1_tight_seed0", 4)])
+def test_sharded_reductions_equal_single_engine_and_reference(S, orc, name, world):
+    """free energy, entropy, EM expectations over shards (all-reduced partials) vs the single engine with the
+    same non-edge evaluation (moment series), and vs the reference golden"""
+    a, r, g, cab, na, psi0, msg0 = _problem(orc, name)
+    sb = _sharded(g, a, cab, na, psi0, msg0, world)
+    res = sb.inference(1e-13, 4000, 1.0)
+    assert res["niter"] >= 0
+    gg = S.load_edge_list(a["path"], a["N"])
+    bp = S.bp_basic()
+    bp.init_messages(S.blockmodel_t(gg, a["Q"], a["dc"]), 0, None, a["true_conf"], a["seed"])
+    bp.expand_bp_params(S.bp_blockmodel_state(cab, na))
+    bp.converge(1e-13, 4000, 1.0)
+    bp.set_nonedge_mode(2, 4)  # series of order 4, as the shards choose at this N
+    f1, p1 = bp.compute_free_energy(parts=True)
+    fk, pk = sb.compute_free_energy(parts=True)
+    assert np.abs(pk - p1).max() < 1e-10 * max(1.0, np.abs(p1).max())
+    # vs the reference golden, whose non-edge term is the exact O(N^2) loop: series truncation bound of SURVEY A.4
+    bound = a["N"] * (max(r["cab"]) / a["N"]) ** 5 / 10.0
+    assert abs(res["free_energy"] - r["f"]) < max(2e-9, 2 * bound) * max(1.0, abs(r["f"]))
+    e1, q1 = bp.compute_entropy(parts=True)
+    ek, qk = sb.compute_entropy(parts=True)
+    if a["dc"]:
+        assert np.isnan(ek) and np.isnan(e1)
+    else:
+        assert np.abs(qk - q1).max() < 1e-10 * max(1.0, np.abs(q1).max())
+        assert abs(ek - r["e"]) < max(2e-8, 20 * bound) * max(1.0, abs(r["e"]))
+    na1, nna1, cab1 = bp.em_expectations()
+    nak, nnak, cabk = sb.em_expectations()
+    import itertools
+    p = list(min(itertools.permutations(range(a["Q"])), key=lambda q: np.abs(nak[list(q)] - na1).max()))
+    assert np.abs(nak[p] - na1).max() < 1e-7 and np.abs(nnak[p] - nna1).max() < 1e-6
+    assert np.abs(cabk[np.ix_(p, p)] - cab1).max() < 1e-8 * max(1.0, np.abs(cab1).max())
+    assert abs(res["overlap"] - bp.compute_overlap()) < 1e-9
