@@ -50,7 +50,10 @@ struct dev_params {
 #define SBMBP_EPT_HI 2  // Q >= 5
 #endif
 #ifndef SBMBP_NT
-#define SBMBP_NT 0  // 1: non-temporal loads/stores on the coalesced message streams
+#define SBMBP_NT 0  // bit 0: non-temporal loads, bit 1: non-temporal stores on the coalesced message streams
+#endif
+#ifndef SBMBP_PSI_WAVES
+#define SBMBP_PSI_WAVES 0  // > 0: min waves per SIMD requested for k_sweep_psi (register cap)
 #endif
 #ifndef SBMBP_FRAME_TPB
 #define SBMBP_FRAME_TPB 256  // threads per workgroup of the frame kernels (multiple of 64)
@@ -89,7 +92,7 @@ template <int Q> __device__ __forceinline__ void store_vec(double *__restrict__ 
 // message streams do not evict the gathered tables from L2 / Infinity Cache
 typedef double v2d __attribute__((ext_vector_type(2)));
 template <int Q> __device__ __forceinline__ void load_vec_stream(const double *__restrict__ p, double (&v)[Q]) {
-#if SBMBP_NT
+#if SBMBP_NT & 1
     if (Q % 2 == 0) {
         const v2d *p2 = reinterpret_cast<const v2d *>(p);
 #pragma unroll
@@ -103,7 +106,7 @@ template <int Q> __device__ __forceinline__ void load_vec_stream(const double *_
 #endif
 }
 template <int Q> __device__ __forceinline__ void store_vec_stream(double *__restrict__ p, const double (&v)[Q]) {
-#if SBMBP_NT
+#if SBMBP_NT & 2
     if (Q % 2 == 0) {
         v2d *p2 = reinterpret_cast<v2d *>(p);
 #pragma unroll
@@ -117,7 +120,7 @@ template <int Q> __device__ __forceinline__ void store_vec_stream(double *__rest
 #endif
 }
 __device__ __forceinline__ uint32_t load_idx_stream(const uint32_t *__restrict__ p) {
-#if SBMBP_NT
+#if SBMBP_NT & 1
     return __builtin_nontemporal_load(p);
 #else
     return *p;
@@ -414,7 +417,12 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
 // (so a period-2 oscillation, whose 2-step difference vanishes, can never pass as converged).
 // ------------------------------------------------------------------------------------------------
 template <int Q>
-__global__ void __launch_bounds__(FTPB)
+__global__ void
+#if SBMBP_PSI_WAVES > 0
+__launch_bounds__(FTPB, SBMBP_PSI_WAVES)
+#else
+__launch_bounds__(FTPB)
+#endif
 k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, double *__restrict__ Mio,
             const double *__restrict__ psi_old, double *__restrict__ psi_new, const uint32_t *__restrict__ blk_row,
             const dev_params *__restrict__ P, int dc, double *__restrict__ partials) {

@@ -1,0 +1,59 @@
+// Measurement aid (not product code): memory floor of the marginal-gather sweep's access pattern at C3 size.
+// Per directed edge: 4-B index (stream), random 32-B gather from an N*4-double table with planted-partition
+// locality (77 % of targets in the row's own quarter), 32-B own message read + write (stream); per row a 32-B write.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <random>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+template <int EPT>
+__global__ void __launch_bounds__(256) probe(const uint32_t* __restrict__ nbr, const double2* __restrict__ psi, double2* __restrict__ M,
+                                             double2* __restrict__ psi_new, uint32_t n_edges, uint32_t n_rows) {
+    const uint32_t base = blockIdx.x * 256 * EPT + threadIdx.x;
+    uint32_t l[EPT]; double2 a[EPT][2], m[EPT][2];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) { uint32_t k = base + j * 256; l[j] = k < n_edges ? nbr[k] : 0; }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) { a[j][0] = psi[size_t(l[j]) * 2]; a[j][1] = psi[size_t(l[j]) * 2 + 1]; }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) { uint32_t k = base + j * 256; if (k < n_edges) { m[j][0] = M[size_t(k) * 2]; m[j][1] = M[size_t(k) * 2 + 1]; } }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        uint32_t k = base + j * 256;
+        if (k < n_edges) {
+            M[size_t(k) * 2] = make_double2(m[j][0].x * 0.5 + a[j][0].x * 0.5, m[j][0].y * 0.5 + a[j][0].y * 0.5);
+            M[size_t(k) * 2 + 1] = make_double2(m[j][1].x * 0.5 + a[j][1].x * 0.5, m[j][1].y * 0.5 + a[j][1].y * 0.5);
+            if (k % 10 == 0 && k / 10 < n_rows) { psi_new[size_t(k / 10) * 2] = a[j][0]; psi_new[size_t(k / 10) * 2 + 1] = a[j][1]; }
+        }
+    }
+}
+int main() {
+    const uint32_t N = 10000000, E = 100000000;
+    std::vector<uint32_t> h(E);
+    std::mt19937_64 rng(1);
+    const uint32_t G = N / 4;
+    for (uint32_t k = 0; k < E; ++k) {
+        uint32_t row = k / 10, g = row / G;
+        uint64_t r = rng();
+        uint32_t tg = ((r & 0xffff) < 0.77 * 65536) ? g : uint32_t((g + 1 + ((r >> 16) % 3)) % 4);
+        h[k] = tg * G + uint32_t((r >> 20) % G);
+    }
+    uint32_t* nbr; double2 *psi, *M, *psin;
+    CK(hipMalloc(&nbr, size_t(E) * 4)); CK(hipMalloc(&psi, size_t(N) * 32)); CK(hipMalloc(&M, size_t(E) * 32)); CK(hipMalloc(&psin, size_t(N) * 32));
+    CK(hipMemcpy(nbr, h.data(), size_t(E) * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(psi, 0, size_t(N) * 32)); CK(hipMemset(M, 0, size_t(E) * 32));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto run = [&](auto kern, int ept, const char* name) {
+        dim3 grid((E + 256 * ept - 1) / (256 * ept));
+        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, grid, dim3(256), 0, 0, nbr, psi, M, psin, E, N);
+        CK(hipEventRecord(e0));
+        for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(kern, grid, dim3(256), 0, 0, nbr, psi, M, psin, E, N);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double bytes = double(E) * (3 * 32 + 4) + double(N) * 40;
+        printf("%s: %.3f ms/launch, algorithmic %.0f GB/s (%.1f%% of 8 TB/s)\n", name, ms / 10, bytes / (ms / 10 * 1e-3) / 1e9, bytes / (ms / 10 * 1e-3) / 8e12 * 100);
+    };
+    run(probe<1>, 1, "probe EPT=1"); run(probe<2>, 2, "probe EPT=2"); run(probe<4>, 4, "probe EPT=4"); run(probe<8>, 8, "probe EPT=8");
+    return 0;
+}
