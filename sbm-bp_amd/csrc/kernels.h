@@ -227,6 +227,30 @@ __device__ __forceinline__ double log_partition(const dev_params *__restrict__ P
     return m + log(s) + double(ex) * 0.6931471805599453;
 }
 
+// Product over a row's edges out of LDS by a whole wave: lanes take strided edges, then a shuffle
+// butterfly multiplies the 64 partial products (every lane ends with the same value: a*b == b*a
+// bitwise, so the result is deterministic). Used for rows above BIG_ROW edges, where the lane-per-row
+// loop would serialise hundreds of LDS reads while the rest of the workgroup waits.
+constexpr int BIG_ROW = 32;
+template <int Q> __device__ __forceinline__ void row_product_wave(const double *sb, int es, int ee, double (&A)[Q]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) A[q] = 1.0;
+    for (int e = es + lane; e < ee; e += 64) {
+        double b[Q];
+        load_vec<Q>(&sb[e * Q], b);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) A[q] *= b[q];
+        rescale_pow2<Q>(A);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) A[q] *= __shfl_xor(A[q], o, 64);
+        rescale_pow2<Q>(A);  // partners hold identical values, so they rescale identically
+    }
+}
+
 // b[q] = sum_t W_il[t][q] m[t]   (belief_propagation.cpp:1000-1012)
 template <int Q, bool DC2>
 __device__ __forceinline__ void edge_field(const dev_params *__restrict__ P, const double (&m)[Q], double didl, double (&b)[Q]) {
@@ -316,19 +340,32 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
     }
     __syncthreads();
 
-    // ---- phase 2: lane per row: A[q] = prod_e b_e[q]; psi_i = normalise(A * eta * F_i)
+    // ---- phase 2: lane per row (a wave per row above BIG_ROW edges): A[q] = prod_e b_e[q];
+    //      psi_i = normalise(A * eta * F_i)
     double Sacc[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) Sacc[q] = 0.0;
+    auto finish_row = [&](int r, double di, double (&A)[Q]) {
+        double pv[Q];
+        const double tot = apply_field<Q>(P, dc, di, A);
+        store_vec<Q>(&sA[r * Q], A);
+        const double inv = 1.0 / tot;
+        const double gi = dc ? di : 1.0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { pv[q] = A[q] * inv; Sacc[q] += gi * pv[q]; }
+        store_vec<Q>(psi + size_t(r0 + r) * Q, pv);
+    };
     for (int r = tid; r < nrows; r += FTPB) {
         const int es = int(srp[r]), ee = int(srp[r + 1]);
         const double di = double(ee - es);
-        const double gi = dc ? di : 1.0;
-        double pv[Q];
         if (sfl[r]) {  // clamped: marginal and out-messages stay as initialised (bp.cpp:1115-1124)
+            double pv[Q];
             load_vec<Q>(psi_old + size_t(r0 + r) * Q, pv);
             store_vec<Q>(psi + size_t(r0 + r) * Q, pv);
-        } else {
+            const double gi = dc ? di : 1.0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) Sacc[q] += gi * pv[q];
+        } else if (ee - es <= BIG_ROW) {
             double A[Q];
 #pragma unroll
             for (int q = 0; q < Q; ++q) A[q] = 1.0;
@@ -339,15 +376,16 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
                 for (int q = 0; q < Q; ++q) A[q] *= b[q];
                 rescale_pow2<Q>(A);
             }
-            const double tot = apply_field<Q>(P, dc, di, A);
-            store_vec<Q>(&sA[r * Q], A);
-            const double inv = 1.0 / tot;
-#pragma unroll
-            for (int q = 0; q < Q; ++q) pv[q] = A[q] * inv;
-            store_vec<Q>(psi + size_t(r0 + r) * Q, pv);
+            finish_row(r, di, A);
         }
-#pragma unroll
-        for (int q = 0; q < Q; ++q) Sacc[q] += gi * pv[q];
+    }
+    for (int r = tid >> 6; r < nrows; r += FWAVES) {  // wave-uniform row index
+        const int es = int(srp[r]), ee = int(srp[r + 1]);
+        if (ee - es > BIG_ROW && !sfl[r]) {
+            double A[Q];
+            row_product_wave<Q>(sb, es, ee, A);
+            if ((tid & 63) == 0) finish_row(r, double(ee - es), A);
+        }
     }
     __syncthreads();
 
@@ -487,34 +525,44 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     }
     __syncthreads();
 
-    // ---- phase 2: lane per row
+    // ---- phase 2: lane per row (a wave per row above BIG_ROW edges)
     double Sacc[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) Sacc[q] = 0.0;
     double md = 0.0;
-    for (int r = tid; r < nrows; r += FTPB) {
-        const int es = int(srp[r]), ee = int(srp[r + 1]);
-        const double di = double(ee - es);
-        const double gi = dc ? di : 1.0;
-        double A[Q], pv[Q];
-#pragma unroll
-        for (int q = 0; q < Q; ++q) A[q] = 1.0;
-        for (int e = es; e < ee; ++e) {
-            double b[Q];
-            load_vec<Q>(&sb[e * Q], b);
-#pragma unroll
-            for (int q = 0; q < Q; ++q) A[q] *= b[q];
-            rescale_pow2<Q>(A);
-        }
+    auto finish_row = [&](int r, double di, double (&A)[Q]) {
+        double pv[Q];
         const double tot = apply_field<Q>(P, dc, di, A);
         store_vec<Q>(&sA[r * Q], A);
         const double inv = 1.0 / tot;
+        const double gi = dc ? di : 1.0;
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            pv[q] = A[q] * inv;
-            Sacc[q] += gi * pv[q];
-        }
+        for (int q = 0; q < Q; ++q) { pv[q] = A[q] * inv; Sacc[q] += gi * pv[q]; }
         store_vec<Q>(psi_new + size_t(r0 + r) * Q, pv);
+    };
+    for (int r = tid; r < nrows; r += FTPB) {
+        const int es = int(srp[r]), ee = int(srp[r + 1]);
+        if (ee - es <= BIG_ROW) {
+            double A[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) A[q] = 1.0;
+            for (int e = es; e < ee; ++e) {
+                double b[Q];
+                load_vec<Q>(&sb[e * Q], b);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) A[q] *= b[q];
+                rescale_pow2<Q>(A);
+            }
+            finish_row(r, double(ee - es), A);
+        }
+    }
+    for (int r = tid >> 6; r < nrows; r += FWAVES) {  // wave-uniform row index
+        const int es = int(srp[r]), ee = int(srp[r + 1]);
+        if (ee - es > BIG_ROW) {
+            double A[Q];
+            row_product_wave<Q>(sb, es, ee, A);
+            if ((tid & 63) == 0) finish_row(r, double(ee - es), A);
+        }
     }
     __syncthreads();
 
