@@ -21,7 +21,7 @@ def build_variant(name, defines):
     vdir = os.path.join(CSRC, "variants")
     os.makedirs(vdir, exist_ok=True)
     out = os.path.join(vdir, "libsbmbp_%s.so" % name)
-    subprocess.check_call([_hipcc(), "-std=c++14", "-O3", "--offload-arch=" + ARCH, "-fPIC", "-shared", "-o", out] +
+    subprocess.check_call([_hipcc(), "-std=c++14", "-O3", "--offload-arch=" + ARCH, "-fPIC", "-shared", "-pthread", "-o", out] +
                           ["-D" + d for d in defines] + srcs)
     return out
 
@@ -46,7 +46,7 @@ def build_lib(force=False, verbose=False):
     deps = srcs + [os.path.join(CSRC, f) for f in ("kernels.h", "host_graph.h")] + [os.path.join(ROOT, "include", "sbmbp.h")]
     out = os.path.join(CSRC, "libsbmbp_hip.so")
     if force or _newer(out, deps):
-        cmd = [_hipcc(), "-std=c++14", "-O3", "--offload-arch=" + ARCH, "-fPIC", "-shared", "-o", out] + srcs
+        cmd = [_hipcc(), "-std=c++14", "-O3", "--offload-arch=" + ARCH, "-fPIC", "-shared", "-pthread", "-o", out] + srcs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

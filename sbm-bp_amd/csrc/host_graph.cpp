@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <random>
+#include <thread>
 
 #include "../../include/sbmbp.h"
 
@@ -15,9 +16,25 @@ static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 const std::string &get_error() { return g_err; }
 
+// run fn(t, lo, hi) over [0, n) split into contiguous pieces on up to `want` threads
+template <typename F> static void parallel_ranges(uint64_t n, unsigned want, F fn) {
+    unsigned nt = std::max(1u, std::min<unsigned>(want, unsigned(n / 65536 + 1)));
+    if (nt == 1) { fn(0u, uint64_t(0), n); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back(fn, t, n * t / nt, n * (t + 1) / nt);
+    for (auto &x : th) x.join();
+}
+
+static unsigned host_threads() {
+    unsigned hc = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(hc ? hc : 1u, 32u));
+}
+
 // Builds the symmetric, de-duplicated, sorted adjacency that edge_to_adj produces with
 // std::set (graph_utilities.cpp:60-77) as flat CSR: bucket by source (counting sort), then
 // sort+unique each row; reverse-edge index (belief_propagation.cpp:254-265) by binary search.
+// The per-row work (sort, unique, compaction, reverse search) runs on host threads; the result does not
+// depend on the thread count.
 int graph_from_pairs(sbmbp_graph &g, const uint32_t *pairs, uint64_t n_pairs, uint32_t n_vertices) {
     uint32_t n = n_vertices;
     for (uint64_t e = 0; e < n_pairs; ++e) {  // the reference grows the adjacency to the largest id (:65-72)
@@ -27,6 +44,7 @@ int graph_from_pairs(sbmbp_graph &g, const uint32_t *pairs, uint64_t n_pairs, ui
         if (b >= n) n = b + 1;
     }
     if (2 * n_pairs >= (uint64_t(1) << 32)) { set_error("more than 2^32-1 directed edges"); return SBMBP_ERR_UNSUPPORTED; }
+    const unsigned nt = host_threads();
     std::vector<uint64_t> cnt(size_t(n) + 1, 0);
     for (uint64_t e = 0; e < n_pairs; ++e) {
         uint32_t a = pairs[2 * e], b = pairs[2 * e + 1];
@@ -43,30 +61,34 @@ int graph_from_pairs(sbmbp_graph &g, const uint32_t *pairs, uint64_t n_pairs, ui
             if (a != b) adj[pos[b]++] = a;
         }
     }
+    // sort + unique every row in place (front of its bucket), remember the unique length
+    std::vector<uint32_t> ulen(n, 0);
+    parallel_ranges(n, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; ++i) {
+            uint32_t *b = adj.data() + cnt[i], *e = adj.data() + cnt[i + 1];
+            std::sort(b, e);
+            ulen[i] = uint32_t(std::unique(b, e) - b);
+        }
+    });
     g.n = n;
     g.row_ptr.assign(size_t(n) + 1, 0);
-    uint64_t w = 0;
     uint32_t maxdeg = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        uint64_t b = cnt[i], e = cnt[i + 1];
-        std::sort(adj.begin() + b, adj.begin() + e);
-        uint64_t start = w;
-        for (uint64_t k = b; k < e; ++k)
-            if (k == b || adj[k] != adj[k - 1]) adj[w++] = adj[k];  // in-place compaction (w <= k always)
-        g.row_ptr[i + 1] = w;
-        maxdeg = std::max(maxdeg, uint32_t(w - start));
-    }
-    adj.resize(w);
-    adj.shrink_to_fit();
-    g.nbr.swap(adj);
+    for (uint32_t i = 0; i < n; ++i) { g.row_ptr[i + 1] = g.row_ptr[i] + ulen[i]; maxdeg = std::max(maxdeg, ulen[i]); }
     g.max_degree = maxdeg;
+    g.nbr.resize(g.row_ptr[n]);
+    parallel_ranges(n, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; ++i) std::copy(adj.data() + cnt[i], adj.data() + cnt[i] + ulen[i], g.nbr.data() + g.row_ptr[i]);
+    });
+    std::vector<uint32_t>().swap(adj);
     g.rev.resize(g.nbr.size());
-    for (uint32_t i = 0; i < n; ++i)
-        for (uint64_t k = g.row_ptr[i]; k < g.row_ptr[i + 1]; ++k) {
-            uint32_t j = g.nbr[k];
-            const uint32_t *b = g.nbr.data() + g.row_ptr[j], *e = g.nbr.data() + g.row_ptr[j + 1];
-            g.rev[k] = uint32_t(std::lower_bound(b, e, i) - g.nbr.data());
-        }
+    parallel_ranges(n, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; ++i)
+            for (uint64_t k = g.row_ptr[i]; k < g.row_ptr[i + 1]; ++k) {
+                uint32_t j = g.nbr[k];
+                const uint32_t *b = g.nbr.data() + g.row_ptr[j], *e = g.nbr.data() + g.row_ptr[j + 1];
+                g.rev[k] = uint32_t(std::lower_bound(b, e, uint32_t(i)) - g.nbr.data());
+            }
+    });
     return SBMBP_OK;
 }
 
