@@ -41,7 +41,7 @@ struct dev_params {
 
 // tunables (A/B'd on MI355X, see DESIGN.md "Tuning log")
 #ifndef SBMBP_EPT_LO
-#define SBMBP_EPT_LO 4  // directed edges per lane, Q <= 2
+#define SBMBP_EPT_LO 2  // directed edges per lane, Q <= 2 (A/B on C2: 2 beats 4 and 1 by ~9 %)
 #endif
 #ifndef SBMBP_EPT_MID
 #define SBMBP_EPT_MID 2  // Q = 3, 4
@@ -285,11 +285,13 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
     __shared__ uint16_t srow[CAP];     // row (within segment) of every edge
     __shared__ uint8_t sfl[RCAP];      // 1 = clamped row
     __shared__ double sred[FWAVES * (Q + 1)];
+    __shared__ int sbig;               // the segment holds a row above BIG_ROW edges
 
     const int tid = threadIdx.x;
     const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
     const int nrows = int(r1 - r0);
     const uint32_t e0 = row_ptr[r0];
+    if (tid == 0) sbig = 0;
     for (int r = tid; r <= nrows; r += FTPB) srp[r] = row_ptr[r0 + r] - e0;
     __syncthreads();
     const int ne = int(srp[nrows]);
@@ -297,6 +299,7 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
 
     for (int r = tid; r < nrows; r += FTPB) {
         const int es = int(srp[r]), ee = int(srp[r + 1]);
+        if (ee - es > BIG_ROW) sbig = 1;
         for (int e = es; e < ee; ++e) srow[e] = uint16_t(r);
         sfl[r] = (clamp != nullptr && clamp[r0 + r] != -1) ? 1 : 0;
     }
@@ -379,6 +382,7 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
             finish_row(r, di, A);
         }
     }
+    if (sbig)  // uniform: written before the barrier that ends phase 1
     for (int r = tid >> 6; r < nrows; r += FWAVES) {  // wave-uniform row index
         const int es = int(srp[r]), ee = int(srp[r + 1]);
         if (ee - es > BIG_ROW && !sfl[r]) {
@@ -471,18 +475,21 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     __shared__ uint32_t srp[RCAP + 1];
     __shared__ uint16_t srow[CAP];
     __shared__ double sred[FWAVES * (Q + 1)];
+    __shared__ int sbig;  // the segment holds a row above BIG_ROW edges
 
     const int tid = threadIdx.x;
     const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
     const int nrows = int(r1 - r0);
     const uint32_t e0 = row_ptr[r0];
+    if (tid == 0) sbig = 0;
     for (int r = tid; r <= nrows; r += FTPB) srp[r] = row_ptr[r0 + r] - e0;
     __syncthreads();
     const int ne = int(srp[nrows]);
-    if (ne > CAP) return;  // hub row: k_sweep_hub (explicit form) owns this segment
+    if (ne > CAP) return;  // hub row: k_sweep_psi_hub owns this segment
 
     for (int r = tid; r < nrows; r += FTPB) {
         const int es = int(srp[r]), ee = int(srp[r + 1]);
+        if (ee - es > BIG_ROW) sbig = 1;
         for (int e = es; e < ee; ++e) srow[e] = uint16_t(r);
     }
 
@@ -556,6 +563,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
             finish_row(r, double(ee - es), A);
         }
     }
+    if (sbig)  // uniform: written before the barrier that ends phase 1
     for (int r = tid >> 6; r < nrows; r += FWAVES) {  // wave-uniform row index
         const int es = int(srp[r]), ee = int(srp[r + 1]);
         if (ee - es > BIG_ROW) {
