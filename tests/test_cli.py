@@ -127,3 +127,64 @@ def test_degree_corrected_run_prints_minus_nan_entropy():
     tok = out.split()
     assert tok[0] == "-nan"  # the reference prints -nan for deg_corr_flag != 0
     assert abs(float(tok[1]) - g["f"]) < 1e-5 and abs(float(tok[2]) - g["overlap"]) < 1e-4
+
+
+MATCHED = ["-l", DS, "-n", 500, 500, "--pa", 0.5, 0.5, "--cab", 5.4545454545454541, 0.54545454545454541, 5.4545454545454541,
+           "-t", 5000, "-m", "infer", "-d", 0, "--precision", 15]
+
+
+def _line(out):
+    e, f, ov, niter = out.split("\n")[0].split()
+    return float(e), float(f), float(ov), int(niter)
+
+
+@pytest.mark.gpu
+def test_clamped_beliefs_flag_i1():
+    """-i 1 --beliefs_path: planted rows are clamped (bp_conditional), message-gather kernel"""
+    g = golden("c1_planted_i1_seed0")["result"]
+    rc, out, err = run(*MATCHED, "-e", 1e-13, "-i", 1, "--beliefs_path", gpath("c1_beliefs.txt"))
+    assert rc == 0 and "Randomly assign" not in err
+    e, f, ov, niter = _line(out)
+    assert abs(f - g["f"]) < 1e-9 and abs(e - g["e"]) < 1e-9 and abs(ov - g["overlap"]) < 1e-9 and niter >= 0
+
+
+@pytest.mark.gpu
+def test_damping_flag_R():
+    g = golden("c1_matched_damped_seed0")["result"]
+    rc, out, err = run(*MATCHED, "-e", 1e-12, "-R", 0.5)
+    assert rc == 0
+    e, f, ov, niter = _line(out)
+    assert abs(f - g["f"]) < 1e-9 and abs(ov - g["overlap"]) < 1e-9 and niter >= 0
+
+
+@pytest.mark.gpu
+def test_beta_flag():
+    g = golden("c1_matched_beta08_seed0")["result"]
+    rc, out, err = run(*MATCHED, "-e", 1e-12, "-b", 0.8)
+    assert rc == 0
+    e, f, ov, niter = _line(out)
+    assert abs(f - g["f"]) < 1e-9 and abs(e - g["e"]) < 1e-9 and abs(ov - g["overlap"]) < 1e-9
+
+
+@pytest.mark.gpu
+def test_deg_corr_flag_2():
+    g = golden("c1_dc2_tight_seed0")["result"]
+    rc, out, err = run("-l", DS, "-n", 500, 500, "--pa", 0.5, 0.5, "--cab", 0.60606060606060608, 0.060606060606060608,
+                       0.60606060606060608, "-t", 5000, "-m", "infer", "-d", 0, "-e", 1e-13, "--deg_corr_flag", 2, "--precision", 15)
+    assert rc == 0
+    tok = out.split()
+    assert tok[0] == "-nan" and abs(float(tok[1]) - g["f"]) < 1e-9 * abs(g["f"]) and abs(float(tok[2]) - g["overlap"]) < 1e-9
+
+
+@pytest.mark.gpu
+def test_fixed_nodes_with_i0_have_no_effect_and_true_conf_file(tmp_path):
+    """-i 0 -f ...: the planted vector is never stored (SURVEY B6), so the result equals the plain run;
+    --true_conf_path with swapped labels leaves the permutation-maximised overlap unchanged"""
+    g = golden("c1_matched_tight_seed0")["result"]
+    tc = tmp_path / "tc.txt"
+    tc.write_text("\n".join(["1"] * 500 + ["0"] * 500) + "\n")
+    rc, out, err = run(*MATCHED, "-e", 1e-13, "-f", 1, 2, 3, "--true_conf_path", tc)
+    assert rc == 0 and err.startswith("Randomly assign initial messages, except certain fixed nodes.\n")
+    assert "Warning! Assign true conf" not in err
+    e, f, ov, niter = _line(out)
+    assert abs(f - g["f"]) < 1e-9 and abs(ov - g["overlap"]) < 1e-9
