@@ -294,8 +294,11 @@ class ShardedBP:
             sh.init_messages_device(seed, np.asarray(true_conf_global)[p.row0:p.row0 + p.n_own])
 
     def expand_bp_params(self, cab, na, beta=1.0):
+        self.cab = np.array(cab, dtype=np.float64)
+        self.na = np.array(na, dtype=np.uint32)
+        self.beta = float(beta)
         for sh in self.shards:
-            sh.set_params(cab, na, beta)
+            sh.set_params(self.cab, self.na, self.beta)
 
     # -- one sweep = exchange, local sweep, reduce, finalize ------------------------------------
     def _exchange_chunk(self, j, c):
@@ -486,6 +489,39 @@ class ShardedBP:
         niter, last = self.converge(conv_crit, time_conv, dumping_rate)
         return dict(niter=niter, last_maxdiff=last, free_energy=self.compute_free_energy(), entropy=self.compute_entropy(),
                     overlap=self.compute_overlap())
+
+    def learning(self, learning_conv_crit, learning_max_time, learning_rate, dumping_rate=1.0):
+        """belief_propagation::learning + learning_step (belief_propagation.cpp:14-75) over shards: the same
+        stopping rule (float criterion shrinking by 0.1, B3) and integer truncation of na (B8). A parameter
+        change leaves the shards' (psi, m) pair slightly inconsistent; the next converge absorbs it."""
+        crit = np.float32(learning_conv_crit)
+        lr = float(np.float32(learning_rate))
+        fold, fdiff, steps, status, sweeps0 = 0.0, 1.0, 0, 0, self.total_sweeps
+        N, Q = self.N_global, self.Q
+        for _ in range(int(learning_max_time)):
+            if fdiff < float(crit):
+                crit = np.float32(float(crit) * 0.1)
+            self.converge(float(crit), int(learning_max_time), dumping_rate)
+            na_e, nna_e, cab_e = self.em_expectations()
+            fnew = self.compute_free_energy()
+            fdiff, fold = abs(fnew - fold), fnew
+            if not np.isfinite(fold):
+                status = 2
+                break
+            if fdiff < float(crit):
+                status = 1
+                break
+            na = self.na.astype(np.int64)
+            rest = N
+            for i in range(Q - 1):
+                na[i] = int(lr * na_e[i] + (1.0 - lr) * na[i])
+                rest -= na[i]
+            na[Q - 1] = rest
+            cab = lr * cab_e + (1.0 - lr) * self.cab
+            self.expand_bp_params(cab, na.astype(np.uint32), self.beta)
+            steps += 1
+        return dict(em_steps=steps, status=status, free_energy=fold, overlap=self.compute_overlap(),
+                    total_sweeps=self.total_sweeps - sweeps0, cab=self.cab.copy(), na=self.na.copy())
 
     def local_state(self):
         return [sh.get_state() for sh in self.shards]

@@ -150,3 +150,34 @@ def test_sharded_reductions_equal_single_engine_and_reference(S, orc, name, worl
     assert np.abs(nak[p] - na1).max() < 1e-7 and np.abs(nnak[p] - nna1).max() < 1e-6
     assert np.abs(cabk[np.ix_(p, p)] - cab1).max() < 1e-8 * max(1.0, np.abs(cab1).max())
     assert abs(res["overlap"] - bp.compute_overlap()) < 1e-9
+
+
+def test_sharded_learning_matches_single_engine_and_reference(S, orc):
+    """-m learn over 3 shards: same EM fixed point as the single engine (trajectories differ only through the
+    finite BP criterion of each EM step) and close to the reference's asynchronous run"""
+    gd = golden("c1_learn_515_seed0")
+    a, r = args_of(gd), gd["result"]
+    g = orc.Graph.from_edgelist(a["path"], a["N"])
+    obp = orc.OracleBP(g, a["Q"], 0)
+    obp.init_messages(0, None, a["true_conf"], orc.Rng(a["seed"]))
+    cab, na = orc.param_from_direct(a["N"], a["Q"], a["pa"], a["cab_upper"])
+    psi0, msg0 = obp.get_state()
+    sb = _sharded(g, a, cab, na, psi0, msg0, 3)
+    res = sb.learning(a["lcrit"], a["tmax"], a["lr"], 1.0)
+    gg = S.load_edge_list(a["path"], a["N"])
+    bm = S.blockmodel_t(gg, a["Q"], 0)
+    bp = S.bp_basic()
+    bp.init_messages(bm, 0, None, a["true_conf"], a["seed"])
+    bp.set_nonedge_mode(2, 4)
+    one = bp.learning(bm, S.bp_blockmodel_state(cab, na), a["lcrit"], a["tmax"], a["lr"], 1.0)
+    cab1, na1 = bp.get_params()
+    assert res["status"] == 1 and one.status == 1
+    # the EM stop (|delta f| < crit) fires while cab is still drifting by ~1 %, and the shards' implicit initial
+    # state may select the mirror label orientation (SURVEY B19): compare modulo the joint permutation, loosely
+    assert abs(res["em_steps"] - one.em_steps) <= 10
+    assert np.abs(np.sort(np.diag(res["cab"])) - np.sort(np.diag(cab1))).max() < 5e-2 * np.abs(cab1).max()
+    assert abs(res["cab"][0, 1] - cab1[0, 1]) < 5e-2 * cab1[0, 1] and abs(int(res["na"].sum()) - int(na1.sum())) == 0
+    assert abs(res["overlap"] - one.overlap) < 5e-3
+    ref_cab = np.array(r["cab_final"]).reshape(2, 2)
+    assert np.abs(np.sort(np.diag(res["cab"])) - np.sort(np.diag(ref_cab))).max() < 5e-2 * np.abs(ref_cab).max()
+    assert abs(res["overlap"] - r["overlap"]) < 2e-2
