@@ -215,8 +215,12 @@ typedef struct sbmbp_conv_state {
 int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *desc, uint32_t Q, uint32_t deg_corr_flag, int device);
 /* start a run of sweeps: uploads parameters, arms the device-side stop flag at `armed_crit` (< 0: never) */
 int sbmbp_shard_begin(sbmbp_engine_t *e, double armed_crit);
-/* gather rows idx[0..n) of the marginal table that sweep j READS into out (device pointers) */
-int sbmbp_shard_pack(sbmbp_engine_t *e, uint32_t j, const uint32_t *d_idx, uint32_t n, double *d_out);
+/* gather rows idx[0..n) of the marginal table that sweep j READS into out (device pointers), ncomp
+ * components per row: Q, or Q-1 to ship the marginals without their last component (they sum to 1) */
+int sbmbp_shard_pack(sbmbp_engine_t *e, uint32_t j, const uint32_t *d_idx, uint32_t n, double *d_out, uint32_t ncomp);
+/* expand n received (staged) rows of ncomp components into the halo rows d_halo_row[0..n) (each < n_halo) of the
+ * table sweep j reads */
+int sbmbp_shard_unpack(sbmbp_engine_t *e, uint32_t j, const double *d_in, const uint32_t *d_halo_row, uint32_t n, uint32_t ncomp);
 /* which of the two marginal buffers sweep j reads (0/1); the other one is written */
 int sbmbp_shard_read_buffer(sbmbp_engine_t *e, uint32_t j);
 /* red[0..Q) = sum over owned rows of g_i psi_i of the buffer sweep j reads (field initialisation) */

@@ -1203,12 +1203,25 @@ int sbmbp_shard_begin(sbmbp_engine_t *e, double armed_crit) {
 
 int sbmbp_shard_read_buffer(sbmbp_engine_t *e, uint32_t j) { return (e && e->sharded) ? ((e->pcur + int(j)) & 1) : SBMBP_ERR_ARG; }
 
-int sbmbp_shard_pack(sbmbp_engine_t *e, uint32_t j, const uint32_t *d_idx, uint32_t n, double *d_out) {
+int sbmbp_shard_pack(sbmbp_engine_t *e, uint32_t j, const uint32_t *d_idx, uint32_t n, double *d_out, uint32_t ncomp) {
     IS_SHARD(e);
+    if (ncomp != e->Q && ncomp + 1 != e->Q) return SBMBP_ERR_ARG;
     if (n == 0) return SBMBP_OK;
     const double *table = e->d_psi[(e->pcur + int(j)) & 1];
-    const uint64_t tot = uint64_t(n) * e->Q;
-    hipLaunchKernelGGL(k_pack_rows, dim3(uint32_t((tot + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, e->stream, table, d_idx, n, int(e->Q), d_out);
+    const uint64_t tot = uint64_t(n) * ncomp;
+    hipLaunchKernelGGL(k_pack_rows, dim3(uint32_t((tot + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, e->stream, table, d_idx, n, int(e->Q),
+                       int(ncomp), d_out);
+    HIPCHK(hipGetLastError());
+    return SBMBP_OK;
+}
+
+int sbmbp_shard_unpack(sbmbp_engine_t *e, uint32_t j, const double *d_in, const uint32_t *d_halo_row, uint32_t n, uint32_t ncomp) {
+    IS_SHARD(e);
+    if ((ncomp != e->Q && ncomp + 1 != e->Q) || n > e->n_halo || (n && !d_halo_row)) return SBMBP_ERR_ARG;
+    if (n == 0) return SBMBP_OK;
+    double *table = e->d_psi[(e->pcur + int(j)) & 1];
+    hipLaunchKernelGGL(k_unpack_rows, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, d_in, n, int(e->Q), int(ncomp), table,
+                       e->N, d_halo_row);
     HIPCHK(hipGetLastError());
     return SBMBP_OK;
 }

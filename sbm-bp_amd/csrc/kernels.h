@@ -683,13 +683,31 @@ k_sweep_psi_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict
     block_reduce_store<Q>(Sacc, md, sred, partials + size_t(hub_blk[blockIdx.x]) * (Q + 1));
 }
 
-// gather rows idx[0..n) of a [rows][Q] table into a contiguous buffer (halo send packing)
+// gather rows idx[0..n) of a [rows][Q] table into a contiguous buffer (halo send packing). With
+// ncomp = Q-1 the last component is dropped: marginals sum to 1, the receiver restores it.
 __global__ void __launch_bounds__(BLOCK)
-k_pack_rows(const double *__restrict__ table, const uint32_t *__restrict__ idx, uint32_t n, int Q, double *__restrict__ out) {
+k_pack_rows(const double *__restrict__ table, const uint32_t *__restrict__ idx, uint32_t n, int Q, int ncomp,
+            double *__restrict__ out) {
     const uint64_t t = uint64_t(blockIdx.x) * BLOCK + threadIdx.x;
-    if (t >= uint64_t(n) * Q) return;
-    const uint32_t r = uint32_t(t / Q), q = uint32_t(t % Q);
+    if (t >= uint64_t(n) * ncomp) return;
+    const uint32_t r = uint32_t(t / ncomp), q = uint32_t(t % ncomp);
     out[t] = table[size_t(idx[r]) * Q + q];
+}
+
+// expand n received rows of ncomp components into table rows row0 + dst[r]: last = 1 - sum (clamped at 0)
+__global__ void __launch_bounds__(BLOCK)
+k_unpack_rows(const double *__restrict__ in, uint32_t n, int Q, int ncomp, double *__restrict__ table, uint32_t row0,
+              const uint32_t *__restrict__ dst) {
+    const uint32_t r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n) return;
+    const size_t row = size_t(row0) + dst[r];
+    double s = 0.0;
+    for (int q = 0; q < ncomp; ++q) {
+        const double v = in[size_t(r) * ncomp + q];
+        table[row * Q + q] = v;
+        s += v;
+    }
+    if (ncomp < Q) table[row * Q + (Q - 1)] = fmax(0.0, 1.0 - s);
 }
 
 // exact 1-step criterion of converge (bp.cpp:1059-1063): max over all message entries |a - b|

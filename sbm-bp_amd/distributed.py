@@ -37,17 +37,24 @@ class ConvState(C.Structure):
 class HipShardBackend:
     """one shard on one GPU: thin wrapper of the sbmbp_shard_* steps; buffers are torch tensors"""
 
-    def __init__(self, plan, Q, dc, device):
+    def __init__(self, plan, Q, dc, device, compress=True):
         import torch
         from sbm_bp_amd.capi import check, load_library
         self._check, self._lib = check, load_library()
         self.torch, self.plan, self.Q, self.dc = torch, plan, Q, dc
+        # halo payload: Q-1 components per marginal (they sum to 1; the receiver restores the last one)
+        self.ncomp = Q - 1 if compress else Q
         self.device = torch.device("cuda", device)
         n_tab = plan.n_own + plan.n_halo
         self.psi = torch.zeros((2, n_tab, Q), dtype=torch.float64, device=self.device)
         self.red = torch.zeros(8192, dtype=torch.float64, device=self.device)
         self.send_idx = torch.as_tensor(plan.send_idx_chunked.astype(np.int32), device=self.device)
-        self.sendbuf = torch.zeros((max(1, len(plan.send_idx_chunked)), Q), dtype=torch.float64, device=self.device)
+        self.sendbuf = torch.zeros((max(1, len(plan.send_idx_chunked)), self.ncomp), dtype=torch.float64, device=self.device)
+        # receive staging buffer, ordered by (chunk, peer); unpack scatters staged rows to their halo rows
+        self.recvbuf = torch.zeros((max(1, plan.n_halo), self.ncomp), dtype=torch.float64, device=self.device)
+        self.stage_to_halo = torch.as_tensor(plan.stage_to_halo.astype(np.int32), device=self.device)
+        self.send_views = [self.sendbuf[int(plan.send_off_c[c]):int(plan.send_off_c[c + 1])] for c in range(plan.n_chunks)]
+        self.recv_views = [self.recvbuf[int(plan.stage_off_c[c]):int(plan.stage_off_c[c + 1])] for c in range(plan.n_chunks)]
         self._row_ptr = np.ascontiguousarray(plan.row_ptr, dtype=np.uint64)
         self._nbr = np.ascontiguousarray(plan.nbr_local, dtype=np.uint32)
         self._chunk_row = np.ascontiguousarray(plan.chunk_row, dtype=np.uint32)
@@ -90,7 +97,15 @@ class HipShardBackend:
         n = int(self.plan.send_counts_cp[c].sum())
         if n:
             self._check(self._lib.sbmbp_shard_pack(self._h, j, C.cast(self.send_idx.data_ptr() + 4 * off, C.POINTER(C.c_uint32)), n,
-                                                   C.cast(self.sendbuf.data_ptr() + 8 * self.Q * off, C.POINTER(C.c_double))))
+                                                   C.cast(self.sendbuf.data_ptr() + 8 * self.ncomp * off, C.POINTER(C.c_double)),
+                                                   self.ncomp))
+
+    def unpack(self, j):
+        """expand the staged halo rows into the table sweep j reads"""
+        if self.plan.n_halo:
+            self._check(self._lib.sbmbp_shard_unpack(self._h, j, C.cast(self.recvbuf.data_ptr(), C.POINTER(C.c_double)),
+                                                     C.cast(self.stage_to_halo.data_ptr(), C.POINTER(C.c_uint32)),
+                                                     self.plan.n_halo, self.ncomp))
 
     def sweep_chunk(self, j, c):
         self._check(self._lib.sbmbp_shard_sweep_chunk(self._h, j, c))
@@ -194,18 +209,12 @@ class TorchDistComm:
     def local_ranks(self):
         return [self.rank]
 
-    def exchange(self, recv_lists, send_lists):
-        """recv_lists[0][p] / send_lists[0][p]: tensor views per peer (may be empty). Grouped
-        non-blocking send/recv (RCCL: one ncclGroup); returns the works to wait on."""
-        ops = []
-        for p in range(self.world):
-            if p == self.rank:
-                continue
-            if send_lists[0][p].shape[0]:
-                ops.append(self.dist.P2POp(self.dist.isend, send_lists[0][p], p))
-            if recv_lists[0][p].shape[0]:
-                ops.append(self.dist.P2POp(self.dist.irecv, recv_lists[0][p], p))
-        return self.dist.batch_isend_irecv(ops) if ops else []
+    def exchange(self, recvs, sends, recv_counts, send_counts):
+        """one all-to-all-v per call: recvs[0]/sends[0] are contiguous row blocks split by peer; returns the work"""
+        if recvs[0].shape[0] == 0 and sends[0].shape[0] == 0 and self.world == 1:
+            return []
+        return [self.dist.all_to_all_single(recvs[0], sends[0], [int(x) for x in recv_counts[0]], [int(x) for x in send_counts[0]],
+                                            async_op=True)]
 
     def all_reduce(self, tensors, op):
         self.dist.all_reduce(tensors[0], op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX)
@@ -223,12 +232,17 @@ class LocalComm:
     def local_ranks(self):
         return list(range(self.world))
 
-    def exchange(self, recv_lists, send_lists):
+    def exchange(self, recvs, sends, recv_counts, send_counts):
+        send_off = [np.concatenate([[0], np.cumsum(sc)]) for sc in send_counts]
         for r in range(self.world):
+            off = 0
             for p in range(self.world):
-                if p != r and recv_lists[r][p].shape[0]:
-                    assert recv_lists[r][p].shape == send_lists[p][r].shape
-                    recv_lists[r][p].copy_(send_lists[p][r])
+                n = int(recv_counts[r][p])
+                if n:
+                    assert int(send_counts[p][r]) == n
+                    s0 = int(send_off[p][r])
+                    recvs[r][off:off + n].copy_(sends[p][s0:s0 + n])
+                off += n
         return []
 
     def all_gather(self, outs, ins):
@@ -302,17 +316,12 @@ class ShardedBP:
 
     # -- one sweep = exchange, local sweep, reduce, finalize ------------------------------------
     def _exchange_chunk(self, j, c):
-        """ship the chunk-c boundary marginals of the table that sweep j reads into the peers' halos"""
+        """ship the chunk-c boundary marginals of the table that sweep j reads: pack, then ONE all-to-all-v of
+        contiguous slices (send buffer and receive staging buffer are ordered by (chunk, peer))"""
         for sh in self.shards:
             sh.pack(j, c)
-        recv, send = [], []
-        for sh, p in zip(self.shards, self.plans):
-            tab = sh.psi[sh.read_buffer(j)]
-            recv.append([tab[p.n_own + int(p.recv_off_cp[c, q]):p.n_own + int(p.recv_off_cp[c, q]) + int(p.recv_counts_cp[c, q])]
-                         for q in range(self.comm.world)])
-            send.append([sh.sendbuf[int(p.send_off_cp[c, q]):int(p.send_off_cp[c, q]) + int(p.send_counts_cp[c, q])]
-                         for q in range(self.comm.world)])
-        return self.comm.exchange(recv, send)
+        return self.comm.exchange([sh.recv_views[c] for sh in self.shards], [sh.send_views[c] for sh in self.shards],
+                                  [p.recv_counts_cp[c] for p in self.plans], [p.send_counts_cp[c] for p in self.plans])
 
     def _reduce(self, n_sum, n_max):
         if n_sum:
@@ -338,6 +347,7 @@ class ShardedBP:
         for w in works:
             w.wait()
         for sh in self.shards:
+            sh.unpack(j + 1)
             sh.sweep_fold()
         self._gather_red()
         for sh in self.shards:
@@ -350,6 +360,7 @@ class ShardedBP:
         for w in works:
             w.wait()
         for sh in self.shards:
+            sh.unpack(0)
             sh.begin(armed)
             sh.field_partial(0)
         self._gather_red()
@@ -442,6 +453,7 @@ class ShardedBP:
         for w in works:
             w.wait()
         for sh in self.shards:
+            sh.unpack(0)
             sh.field_partial(0)
         self._gather_red()
         for sh in self.shards:

@@ -96,6 +96,12 @@ class ShardPlan:
             for c in range(Cn):
                 self.recv_counts_cp[c, p] = cut[c + 1] - cut[c]
                 self.recv_off_cp[c, p] = halo_off[p] + cut[c]
+        # receive staging buffer ordered by (chunk, peer): one contiguous slice per chunk, so a chunk's exchange is
+        # a single all_to_all_single; stage_to_halo[r] = halo row of staged row r (the unpack kernel scatters)
+        self.stage_off_c = np.concatenate([[0], np.cumsum(self.recv_counts_cp.sum(1))])
+        pieces = [np.arange(self.recv_off_cp[c, p], self.recv_off_cp[c, p] + self.recv_counts_cp[c, p]) for c in range(Cn) for p in range(W)]
+        self.stage_to_halo = (np.concatenate(pieces) if pieces else np.zeros(0)).astype(np.int64)
+        self.send_off_c = np.concatenate([[0], np.cumsum(self.send_counts_cp.sum(1))])
 
     def summary(self):
         return dict(rank=self.rank, n_own=self.n_own, n_halo=self.n_halo, n_edges=self.n_edges,

@@ -17,7 +17,11 @@ class NumpyShardBackend:
         n_tab = plan.n_own + plan.n_halo
         self.psi = torch.zeros((2, n_tab, Q), dtype=torch.float64)
         self.red = torch.zeros(8192, dtype=torch.float64)
-        self.sendbuf = torch.zeros((max(1, len(plan.send_idx_chunked)), Q), dtype=torch.float64)
+        self.ncomp = Q - 1  # compressed halo payload, as the HIP backend's default
+        self.sendbuf = torch.zeros((max(1, len(plan.send_idx_chunked)), self.ncomp), dtype=torch.float64)
+        self.recvbuf = torch.zeros((max(1, plan.n_halo), self.ncomp), dtype=torch.float64)
+        self.send_views = [self.sendbuf[int(plan.send_off_c[c]):int(plan.send_off_c[c + 1])] for c in range(plan.n_chunks)]
+        self.recv_views = [self.recvbuf[int(plan.stage_off_c[c]):int(plan.stage_off_c[c + 1])] for c in range(plan.n_chunks)]
         self.M = [np.zeros((plan.n_edges, Q)), np.zeros((plan.n_edges, Q))]
         self.cur = self.pcur = 0
         self.st = State()
@@ -55,7 +59,15 @@ class NumpyShardBackend:
         off, n = int(self.plan.send_off_cp[c, 0]), int(self.plan.send_counts_cp[c].sum())
         if n:
             idx = torch.from_numpy(self.plan.send_idx_chunked[off:off + n])
-            self.sendbuf[off:off + n] = self.psi[self.read_buffer(j)][idx]
+            self.sendbuf[off:off + n] = self.psi[self.read_buffer(j)][idx][:, :self.ncomp]
+
+    def unpack(self, j):
+        nh = self.plan.n_halo
+        if nh:
+            tab = self.psi[self.read_buffer(j)]
+            dst = torch.from_numpy(self.plan.n_own + self.plan.stage_to_halo)
+            tab[dst, :self.ncomp] = self.recvbuf[:nh]
+            tab[dst, self.ncomp] = torch.clamp(1.0 - self.recvbuf[:nh].sum(1), min=0.0)
 
     def _g(self):
         return self.plan.deg.astype(np.float64) if self.dc else np.ones(self.plan.n_own)
