@@ -922,7 +922,7 @@ int sbmbp_set_state(sbmbp_engine_t *e, const double *psi, const double *msg_out)
     // a sharded engine takes the declared state as (psi^0, m^-1): sweep 0 reads the buffer it then overwrites
     if (msg_out && e->E2 && e->sharded) HIPCHK(hipMemcpyAsync(e->d_M[e->cur ^ 1], msg_out, e->E2 * e->Q * 8, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (psi && msg_out) e->have_state = true;
+    if (psi && (msg_out || e->E2 == 0)) e->have_state = true;  // a graph without edges has no messages
     e->field_fresh = false;
     e->psi_consistent = false;
     return SBMBP_OK;

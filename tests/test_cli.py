@@ -188,3 +188,11 @@ def test_fixed_nodes_with_i0_have_no_effect_and_true_conf_file(tmp_path):
     assert "Warning! Assign true conf" not in err
     e, f, ov, niter = _line(out)
     assert abs(f - g["f"]) < 1e-9 and abs(ov - g["overlap"]) < 1e-9
+
+
+def test_vertex_id_beyond_n_is_rejected(tmp_path):
+    """ids >= sum(n) make the reference index out of range; here it is an error before any GPU work"""
+    p = tmp_path / "g.edgelist"
+    p.write_text("0 1\n2 12\n")
+    rc, out, err = run("-l", p, "-n", 5, 5, "--epsilon_c", 0.1, 3, "-m", "infer")
+    assert rc == 1 and out == "" and "vertex ids >= sum(n) = 10" in err
