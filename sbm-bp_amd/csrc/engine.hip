@@ -120,7 +120,7 @@ int ensure_small(sbmbp_engine *e, size_t doubles) {
     return SBMBP_OK;
 }
 
-constexpr uint32_t FOLD_BLOCKS = 256, FOLD_STRIDE_MAX = 64;
+constexpr uint32_t FOLD_BLOCKS = 256, FOLD_STRIDE_MAX = 128;
 
 // two-stage fold: when there are many partial rows, reduce them to FOLD_BLOCKS rows first.
 // Returns the pointer/row count the final single-workgroup stage should read.
@@ -389,6 +389,15 @@ int fold_to_device(sbmbp_engine *e, uint32_t rows, uint32_t cols, uint32_t strid
     return SBMBP_OK;
 }
 
+// [rows][cols] partials (stride = cols) -> d_out[cols]: row-parallel two-stage fold for narrow matrices,
+// column-parallel serial fold for wide ones (moment tensors)
+int fold_matrix_to_device(sbmbp_engine *e, uint32_t rows, uint32_t cols, double *d_out) {
+    if (cols <= FOLD_STRIDE_MAX) return fold_to_device(e, rows, cols, cols, d_out);
+    hipLaunchKernelGGL(k_fold_columns, dim3((cols + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_partials, rows, cols, d_out);
+    HIPCHK(hipGetLastError());
+    return SBMBP_OK;
+}
+
 int refresh_field(sbmbp_engine *e) {
     if (!e->have_params || !e->have_state) { set_error("engine has no parameters or no state"); return SBMBP_ERR_STATE; }
     CHK(launch_field(e, 2));
@@ -489,14 +498,13 @@ int nonedge_terms(sbmbp_engine *e, bool want_entropy, double out[2]) {
         (void)Kent;
         int T = 0, sz = 1;
         for (int k = 1; k <= K; ++k) { sz *= int(Q); T += sz; }
-        const uint32_t rows_per_blk = 8192;
+        const uint32_t rows_per_blk = 512;  // one thread per output entry loops over staged rows: keep chunks small, workgroups many
         const uint32_t nb = std::max<uint32_t>(1, (N + rows_per_blk - 1) / rows_per_blk);
         CHK(ensure_partials(e, size_t(nb) * T));
         CHK(ensure_small(e, size_t(T)));
         hipLaunchKernelGGL(k_moments, dim3(nb), dim3(BLOCK), 0, e->stream, e->d_psi[e->pcur], N, int(Q), K, rows_per_blk, T, e->d_partials);
-        hipLaunchKernelGGL(k_fold_columns, dim3((T + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_partials, nb,
-                           uint32_t(T), e->d_small);
         HIPCHK(hipGetLastError());
+        CHK(fold_matrix_to_device(e, nb, uint32_t(T), e->d_small));
         std::vector<double> Mk(T);
         HIPCHK(hipMemcpyAsync(Mk.data(), e->d_small, size_t(T) * 8, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -530,14 +538,14 @@ int nonedge_terms(sbmbp_engine *e, bool want_entropy, double out[2]) {
 int row_sums(sbmbp_engine *e, std::vector<double> &out /* 2Q + Q*Q */) {
     const uint32_t Q = e->Q;
     const uint32_t T = 2 * Q + Q * Q;
-    const uint32_t rows_per_blk = 8192;
+    const uint32_t rows_per_blk = 512;  // one thread per output entry loops over staged rows: keep chunks small, workgroups many
     const uint32_t nb = std::max<uint32_t>(1, (e->N + rows_per_blk - 1) / rows_per_blk);
     CHK(ensure_partials(e, size_t(nb) * T));
     CHK(ensure_small(e, T));
     DISPATCH_Q(Q, hipLaunchKernelGGL((k_row_sums<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_psi[e->pcur],
                                      e->d_true, e->N, rows_per_blk, e->d_partials));
-    hipLaunchKernelGGL(k_fold_columns, dim3((T + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_partials, nb, T, e->d_small);
     HIPCHK(hipGetLastError());
+    CHK(fold_matrix_to_device(e, nb, T, e->d_small));
     out.resize(T);
     HIPCHK(hipMemcpyAsync(out.data(), e->d_small, size_t(T) * 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -1311,14 +1319,13 @@ int sbmbp_shard_msgdiff_partial(sbmbp_engine_t *e) {
 int sbmbp_shard_rowsums_partial(sbmbp_engine_t *e) {
     IS_SHARD(e);
     const uint32_t Q = e->Q, T = 2 * Q + Q * Q;
-    const uint32_t rows_per_blk = 8192;
+    const uint32_t rows_per_blk = 512;  // one thread per output entry loops over staged rows: keep chunks small, workgroups many
     const uint32_t nb = std::max<uint32_t>(1, (e->N + rows_per_blk - 1) / rows_per_blk);
     CHK(ensure_partials(e, size_t(nb) * T));
     DISPATCH_Q(Q, hipLaunchKernelGGL((k_row_sums<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_psi[e->pcur],
                                      e->d_true, e->N, rows_per_blk, e->d_partials));
-    hipLaunchKernelGGL(k_fold_columns, dim3((T + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_partials, nb, T, e->d_red);
     HIPCHK(hipGetLastError());
-    return SBMBP_OK;
+    return fold_matrix_to_device(e, nb, T, e->d_red);
 }
 
 int sbmbp_shard_poll(sbmbp_engine_t *e, sbmbp_conv_state *out) {
@@ -1437,12 +1444,12 @@ int sbmbp_shard_nonedge_partial(sbmbp_engine_t *e, int want_entropy, uint32_t *n
     if (!e->d_mats) CHK(dev_alloc(e, &e->d_mats, 3 * Q * Q));
     HIPCHK(hipMemcpyAsync(e->d_mats, mats.data(), mats.size() * 8, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    const uint32_t rows_per_blk = 8192;
+    const uint32_t rows_per_blk = 512;  // one thread per output entry loops over staged rows: keep chunks small, workgroups many
     const uint32_t nb = std::max<uint32_t>(1, (e->N + rows_per_blk - 1) / rows_per_blk);
     CHK(ensure_partials(e, size_t(nb) * T));
     hipLaunchKernelGGL(k_moments, dim3(nb), dim3(BLOCK), 0, e->stream, e->d_psi[e->pcur], e->N, int(Q), K, rows_per_blk, T, e->d_partials);
-    hipLaunchKernelGGL(k_fold_columns, dim3((T + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_partials, nb, uint32_t(T), e->d_red);
     HIPCHK(hipGetLastError());
+    CHK(fold_matrix_to_device(e, nb, uint32_t(T), e->d_red));
     CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (NE_NP + 1)));
     DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_adj<QQ>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
                                      e->d_psi[e->pcur], e->d_mats, e->d_mats + 2 * Q * Q, e->d_blk_row, 1.0 / double(e->Nglob),
