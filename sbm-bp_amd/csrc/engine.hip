@@ -48,7 +48,7 @@ struct sbmbp_engine {
     std::vector<uint32_t> chunk_blk, chunk_hub;  // per row chunk: first segment / first hub row (n_chunks+1 entries)
     // graph + work decomposition in HBM
     uint32_t *d_row_ptr = nullptr, *d_rev = nullptr, *d_nbr = nullptr, *d_src = nullptr;
-    uint32_t *d_blk_row = nullptr, *d_hub_row = nullptr, *d_hub_blk = nullptr, *d_true = nullptr;
+    uint32_t *d_blk_row = nullptr, *d_blk_e0 = nullptr, *d_hub_row = nullptr, *d_hub_blk = nullptr, *d_true = nullptr;
     int32_t *d_clamp = nullptr;
     uint32_t n_blk = 0, n_hub = 0;
     // state in HBM
@@ -212,14 +212,14 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form) {
     }
     if (psi_form) {
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
-                                            Mnew, psi_old, psi_new, e->d_blk_row, e->d_P, int(e->dc), e->d_partials));
+                                            Mnew, psi_old, psi_new, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), e->d_partials));
     } else if (e->dc == 2) {
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, true>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
-                                            e->d_rev, e->d_nbr, Mold, Mnew, psi_old, psi_new, clamp, e->d_blk_row, e->d_P,
+                                            e->d_rev, e->d_nbr, Mold, Mnew, psi_old, psi_new, clamp, e->d_blk_row, e->d_blk_e0, e->d_P,
                                             1, damp, e->d_partials));
     } else {
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, false>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
-                                            e->d_rev, e->d_nbr, Mold, Mnew, psi_old, psi_new, clamp, e->d_blk_row, e->d_P,
+                                            e->d_rev, e->d_nbr, Mold, Mnew, psi_old, psi_new, clamp, e->d_blk_row, e->d_blk_e0, e->d_P,
                                             int(e->dc), damp, e->d_partials));
     }
     if (e->timing) HIPCHK(hipEventRecord(e1, e->stream));
@@ -794,12 +794,13 @@ int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint3
     TRY(dev_alloc(e, &e->d_rev, e->E2));
     TRY(dev_alloc(e, &e->d_nbr, e->E2));
     TRY(dev_alloc(e, &e->d_blk_row, blk_row.size()));
+    TRY(dev_alloc(e, &e->d_blk_e0, blk_row.size()));
     TRY(dev_alloc(e, &e->d_hub_row, hub_row.size()));
     TRY(dev_alloc(e, &e->d_hub_blk, hub_blk.size()));
     TRY(dev_alloc(e, &e->d_true, e->N));
     TRY(dev_alloc(e, &e->d_clamp, e->N));
-    TRY(dev_alloc(e, &e->d_M[0], e->E2 * Q));
-    TRY(dev_alloc(e, &e->d_M[1], e->E2 * Q));
+    TRY(dev_alloc(e, &e->d_M[0], std::max<uint64_t>(e->E2, 1) * Q));  // >= one Q-vector: the sweep's loads are branch-free
+    TRY(dev_alloc(e, &e->d_M[1], std::max<uint64_t>(e->E2, 1) * Q));
     TRY(dev_alloc(e, &e->d_psi[0], size_t(e->N) * Q));
     TRY(dev_alloc(e, &e->d_psi[1], size_t(e->N) * Q));
     TRY(dev_alloc(e, &e->d_P, 1));
@@ -814,7 +815,10 @@ int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint3
         TRYHIP(hipMemcpyAsync(e->d_rev, g->rev.data(), e->E2 * 4, hipMemcpyHostToDevice, e->stream));
         TRYHIP(hipMemcpyAsync(e->d_nbr, g->nbr.data(), e->E2 * 4, hipMemcpyHostToDevice, e->stream));
     }
+    std::vector<uint32_t> blk_e0(blk_row.size());  // edge offset of every segment start, next to the row range
+    for (size_t b = 0; b < blk_row.size(); ++b) blk_e0[b] = rp32[blk_row[b]];
     TRYHIP(hipMemcpyAsync(e->d_blk_row, blk_row.data(), blk_row.size() * 4, hipMemcpyHostToDevice, e->stream));
+    TRYHIP(hipMemcpyAsync(e->d_blk_e0, blk_e0.data(), blk_e0.size() * 4, hipMemcpyHostToDevice, e->stream));
     if (e->n_hub) {
         TRYHIP(hipMemcpyAsync(e->d_hub_row, hub_row.data(), hub_row.size() * 4, hipMemcpyHostToDevice, e->stream));
         TRYHIP(hipMemcpyAsync(e->d_hub_blk, hub_blk.data(), hub_blk.size() * 4, hipMemcpyHostToDevice, e->stream));
@@ -843,7 +847,7 @@ void sbmbp_destroy(sbmbp_engine_t *e) {
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->ext_psi) e->d_psi[0] = e->d_psi[1] = nullptr;  // caller-owned
-    void *ptrs[] = {e->d_row_ptr, e->d_rev, e->d_nbr, e->d_src, e->d_blk_row, e->d_hub_row, e->d_hub_blk, e->d_true,
+    void *ptrs[] = {e->d_row_ptr, e->d_rev, e->d_nbr, e->d_src, e->d_blk_row, e->d_blk_e0, e->d_hub_row, e->d_hub_blk, e->d_true,
                     e->d_clamp, e->d_M[0], e->d_M[1], e->d_psi[0], e->d_psi[1], e->d_Min, e->d_P, e->d_partials, e->d_small, e->d_hist, e->d_mats,
                     e->d_stage};
     for (void *p : ptrs) if (p) hipFree(p);
@@ -1175,11 +1179,12 @@ int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *d, uint32_t
     TRY(dev_alloc(e, &e->d_row_ptr, rp32.size()));
     TRY(dev_alloc(e, &e->d_nbr, e->E2));
     TRY(dev_alloc(e, &e->d_blk_row, blk_row.size()));
+    TRY(dev_alloc(e, &e->d_blk_e0, blk_row.size()));
     TRY(dev_alloc(e, &e->d_hub_row, hub_row.size()));
     TRY(dev_alloc(e, &e->d_hub_blk, hub_blk.size()));
     TRY(dev_alloc(e, &e->d_true, e->N));
-    TRY(dev_alloc(e, &e->d_M[0], e->E2 * Q));
-    TRY(dev_alloc(e, &e->d_M[1], e->E2 * Q));
+    TRY(dev_alloc(e, &e->d_M[0], std::max<uint64_t>(e->E2, 1) * Q));  // >= one Q-vector: the sweep's loads are branch-free
+    TRY(dev_alloc(e, &e->d_M[1], std::max<uint64_t>(e->E2, 1) * Q));
     TRY(dev_alloc(e, &e->d_P, 1));
     e->hist_cap = 4096;
     TRY(dev_alloc(e, &e->d_hist, e->hist_cap));
@@ -1188,7 +1193,10 @@ int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *d, uint32_t
     TRY(dev_alloc(e, &e->d_stage, size_t(FOLD_BLOCKS) * FOLD_STRIDE_MAX));
     TRYHIP(hipMemcpyAsync(e->d_row_ptr, rp32.data(), rp32.size() * 4, hipMemcpyHostToDevice, e->stream));
     if (e->E2) TRYHIP(hipMemcpyAsync(e->d_nbr, d->nbr_local, e->E2 * 4, hipMemcpyHostToDevice, e->stream));
+    std::vector<uint32_t> blk_e0(blk_row.size());  // edge offset of every segment start, next to the row range
+    for (size_t b = 0; b < blk_row.size(); ++b) blk_e0[b] = rp32[blk_row[b]];
     TRYHIP(hipMemcpyAsync(e->d_blk_row, blk_row.data(), blk_row.size() * 4, hipMemcpyHostToDevice, e->stream));
+    TRYHIP(hipMemcpyAsync(e->d_blk_e0, blk_e0.data(), blk_e0.size() * 4, hipMemcpyHostToDevice, e->stream));
     if (e->n_hub) {
         TRYHIP(hipMemcpyAsync(e->d_hub_row, hub_row.data(), hub_row.size() * 4, hipMemcpyHostToDevice, e->stream));
         TRYHIP(hipMemcpyAsync(e->d_hub_blk, hub_blk.data(), hub_blk.size() * 4, hipMemcpyHostToDevice, e->stream));
@@ -1269,7 +1277,7 @@ int sbmbp_shard_sweep_chunk(sbmbp_engine_t *e, uint32_t j, uint32_t c) {
     }
     if (nb)
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ>), dim3(nb), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr, Mio,
-                                            psi_old, psi_new, e->d_blk_row + b0, e->d_P, int(e->dc),
+                                            psi_old, psi_new, e->d_blk_row + b0, e->d_blk_e0 + b0, e->d_P, int(e->dc),
                                             e->d_partials + size_t(b0) * (e->Q + 1)));
     if (e->timing && nb) HIPCHK(hipEventRecord(e1, e->stream));
     if (nh)

@@ -276,8 +276,7 @@ __global__ void __launch_bounds__(FTPB)
 k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr,
         const double *__restrict__ Mold, double *__restrict__ Mnew, const double *__restrict__ psi_old,
         double *__restrict__ psi, const int32_t *__restrict__ clamp, const uint32_t *__restrict__ blk_row,
-        const dev_params *__restrict__ P, int dc, double damp, double *__restrict__ partials) {
-    if (P->stop) return;
+        const uint32_t *__restrict__ blk_e0, const dev_params *__restrict__ P, int dc, double damp, double *__restrict__ partials) {
     constexpr int EPT = frame_cfg<Q>::EPT, CAP = frame_cfg<Q>::CAP, RCAP = frame_cfg<Q>::RCAP;
     __shared__ double sb[CAP * Q];     // b_e[q] of every edge of the segment
     __shared__ double sA[RCAP * Q];    // unnormalised marginal of every row
@@ -287,58 +286,58 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
     __shared__ double sred[FWAVES * (Q + 1)];
     __shared__ int sbig;               // the segment holds a row above BIG_ROW edges
 
+    // bounds and stop flag from one level of scalar loads; streams issued before the row offsets -> LDS fill
     const int tid = threadIdx.x;
+    const int stop = P->stop;
     const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
-    const int nrows = int(r1 - r0);
-    const uint32_t e0 = row_ptr[r0];
-    if (tid == 0) sbig = 0;
-    for (int r = tid; r <= nrows; r += FTPB) srp[r] = row_ptr[r0 + r] - e0;
-    __syncthreads();
-    const int ne = int(srp[nrows]);
-    if (ne > CAP) return;  // hub row: k_sweep_hub owns this segment (uniform exit, before any other barrier)
+    const uint32_t e0 = blk_e0[blockIdx.x];
+    const int nrows = int(r1 - r0), ne = int(blk_e0[blockIdx.x + 1] - e0);
+    if (stop || ne > CAP) return;  // stopped run, or hub row (k_sweep_hub owns it): uniform exit before any barrier
 
+    // ---- phase 1: lane per directed edge: gather incoming message, b = W^T m -> LDS (branch-free loads,
+    // see k_sweep_psi)
+    constexpr int RPT = RCAP / FTPB + 1;
+    double mo[EPT][Q];
+    uint32_t rk[EPT], kk[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int le = j * FTPB + tid;
+        kk[j] = (ne > 0) ? e0 + uint32_t(le < ne ? le : 0) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) rk[j] = load_idx_stream(rev + kk[j]);
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) load_vec_stream<Q>(Mold + size_t(kk[j]) * Q, mo[j]);
+    uint32_t rpv[RPT];
+#pragma unroll
+    for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; rpv[t] = row_ptr[r0 + uint32_t(r < nrows ? r : nrows)]; }
+    double mi[EPT][Q];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) load_vec<Q>(Mold + size_t(rk[j]) * Q, mi[j]);
+    if (tid == 0) sbig = 0;
+#pragma unroll
+    for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; if (r <= nrows) srp[r] = rpv[t] - e0; }
+    __syncthreads();  // srp visible
     for (int r = tid; r < nrows; r += FTPB) {
         const int es = int(srp[r]), ee = int(srp[r + 1]);
         if (ee - es > BIG_ROW) sbig = 1;
         for (int e = es; e < ee; ++e) srow[e] = uint16_t(r);
         sfl[r] = (clamp != nullptr && clamp[r0 + r] != -1) ? 1 : 0;
     }
-    __syncthreads();
-
-    // ---- phase 1: lane per directed edge: gather incoming message, b = W^T m -> LDS
-    double mo[EPT][Q];
-    {
-        uint32_t rk[EPT];
+    if (DC2) __syncthreads();  // per-edge weights need the edge -> row map
 #pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-            const int le = j * FTPB + tid;
-            rk[j] = (le < ne) ? load_idx_stream(rev + e0 + le) : 0u;
-        }
-        double mi[EPT][Q];
-#pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-            const int le = j * FTPB + tid;
-            if (le < ne) load_vec<Q>(Mold + size_t(rk[j]) * Q, mi[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-            const int le = j * FTPB + tid;
-            if (le < ne) load_vec_stream<Q>(Mold + size_t(e0 + le) * Q, mo[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-            const int le = j * FTPB + tid;
-            if (le < ne) {
-                double didl = 0.0;
-                if (DC2) {
-                    const int r = srow[le];
-                    const uint32_t l = nbr[e0 + le];
-                    didl = double(srp[r + 1] - srp[r]) * double(row_ptr[l + 1] - row_ptr[l]);
-                }
-                double b[Q];
-                edge_field<Q, DC2>(P, mi[j], didl, b);
-                store_vec<Q>(&sb[le * Q], b);
+    for (int j = 0; j < EPT; ++j) {
+        const int le = j * FTPB + tid;
+        if (le < ne) {
+            double didl = 0.0;
+            if (DC2) {
+                const int r = srow[le];
+                const uint32_t l = nbr[e0 + le];
+                didl = double(srp[r + 1] - srp[r]) * double(row_ptr[l + 1] - row_ptr[l]);
             }
+            double b[Q];
+            edge_field<Q, DC2>(P, mi[j], didl, b);
+            store_vec<Q>(&sb[le * Q], b);
         }
     }
     __syncthreads();
@@ -467,8 +466,7 @@ __launch_bounds__(FTPB)
 #endif
 k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, double *__restrict__ Mio,
             const double *__restrict__ psi_old, double *__restrict__ psi_new, const uint32_t *__restrict__ blk_row,
-            const dev_params *__restrict__ P, int dc, double *__restrict__ partials) {
-    if (P->stop) return;
+            const uint32_t *__restrict__ blk_e0, const dev_params *__restrict__ P, int dc, double *__restrict__ partials) {
     constexpr int EPT = frame_cfg<Q>::EPT, CAP = frame_cfg<Q>::CAP, RCAP = frame_cfg<Q>::RCAP;
     __shared__ double sb[CAP * Q];
     __shared__ double sA[RCAP * Q];
@@ -477,57 +475,60 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     __shared__ double sred[FWAVES * (Q + 1)];
     __shared__ int sbig;  // the segment holds a row above BIG_ROW edges
 
+    // Segment bounds (row range and edge range side by side) and the stop flag come from one level of scalar
+    // loads, so the streams are issued at once; the row offsets -> LDS fill, which only the later phases need,
+    // overlaps them.
     const int tid = threadIdx.x;
+    const int stop = P->stop;
     const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
-    const int nrows = int(r1 - r0);
-    const uint32_t e0 = row_ptr[r0];
-    if (tid == 0) sbig = 0;
-    for (int r = tid; r <= nrows; r += FTPB) srp[r] = row_ptr[r0 + r] - e0;
-    __syncthreads();
-    const int ne = int(srp[nrows]);
-    if (ne > CAP) return;  // hub row: k_sweep_psi_hub owns this segment
+    const uint32_t e0 = blk_e0[blockIdx.x];
+    const int nrows = int(r1 - r0), ne = int(blk_e0[blockIdx.x + 1] - e0);
+    if (stop || ne > CAP) return;  // stopped run, or hub row (k_sweep_psi_hub owns it): uniform exit before any barrier
 
+    // ---- phase 1: lane per directed edge. Loads are branch-free (inactive lanes re-read the segment's first
+    // edge) so the compiler issues them back to back: index stream, own-message stream, row offsets (kept in
+    // registers), then the gathers as soon as the indices are back — no LDS write or wait in between.
+    constexpr int RPT = RCAP / FTPB + 1;
+    double mo[EPT][Q];
+    uint32_t nl[EPT], kk[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int le = j * FTPB + tid;
+        kk[j] = (ne > 0) ? e0 + uint32_t(le < ne ? le : 0) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) nl[j] = load_idx_stream(nbr + kk[j]);
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) load_vec_stream<Q>(Mio + size_t(kk[j]) * Q, mo[j]);
+    uint32_t rpv[RPT];
+#pragma unroll
+    for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; rpv[t] = row_ptr[r0 + uint32_t(r < nrows ? r : nrows)]; }
+    double pl[EPT][Q];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) load_vec<Q>(psi_old + size_t(nl[j]) * Q, pl[j]);
+    if (tid == 0) sbig = 0;
+#pragma unroll
+    for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; if (r <= nrows) srp[r] = rpv[t] - e0; }
+    __syncthreads();  // srp visible
     for (int r = tid; r < nrows; r += FTPB) {
         const int es = int(srp[r]), ee = int(srp[r + 1]);
         if (ee - es > BIG_ROW) sbig = 1;
         for (int e = es; e < ee; ++e) srow[e] = uint16_t(r);
     }
-
-    // ---- phase 1: lane per directed edge
-    double mo[EPT][Q];
-    {
-        uint32_t nl[EPT];
 #pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-            const int le = j * FTPB + tid;
-            nl[j] = (le < ne) ? load_idx_stream(nbr + e0 + le) : 0u;
-        }
-        double pl[EPT][Q];
+    for (int j = 0; j < EPT; ++j) {
+        const int le = j * FTPB + tid;
+        if (le < ne) {
+            double bo[Q], inc[Q], b[Q];
+            edge_field<Q, false>(P, mo[j], 0.0, bo);  // what l saw of i's message at sweep t-1
+            double tot = 0.0;
 #pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-            const int le = j * FTPB + tid;
-            if (le < ne) load_vec<Q>(psi_old + size_t(nl[j]) * Q, pl[j]);
-        }
+            for (int s = 0; s < Q; ++s) { inc[s] = pl[j][s] / bo[s]; tot += inc[s]; }
+            const double inv = 1.0 / tot;
 #pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-            const int le = j * FTPB + tid;
-            if (le < ne) load_vec_stream<Q>(Mio + size_t(e0 + le) * Q, mo[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-            const int le = j * FTPB + tid;
-            if (le < ne) {
-                double bo[Q], inc[Q], b[Q];
-                edge_field<Q, false>(P, mo[j], 0.0, bo);  // what l saw of i's message at sweep t-1
-                double tot = 0.0;
-#pragma unroll
-                for (int s = 0; s < Q; ++s) { inc[s] = pl[j][s] / bo[s]; tot += inc[s]; }
-                const double inv = 1.0 / tot;
-#pragma unroll
-                for (int s = 0; s < Q; ++s) inc[s] *= inv;  // m^t_{l->i}
-                edge_field<Q, false>(P, inc, 0.0, b);
-                store_vec<Q>(&sb[le * Q], b);
-            }
+            for (int s = 0; s < Q; ++s) inc[s] *= inv;  // m^t_{l->i}
+            edge_field<Q, false>(P, inc, 0.0, b);
+            store_vec<Q>(&sb[le * Q], b);
         }
     }
     __syncthreads();

@@ -6,11 +6,15 @@
 #include <cstdlib>
 #include <vector>
 #include <random>
+#include <algorithm>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
-template <int EPT>
+template <int EPT, int LOOKUP = 0>
 __global__ void __launch_bounds__(256) probe(const uint32_t* __restrict__ nbr, const double2* __restrict__ psi, double2* __restrict__ M,
-                                             double2* __restrict__ psi_new, uint32_t n_edges, uint32_t n_rows) {
-    const uint32_t base = blockIdx.x * 256 * EPT + threadIdx.x;
+                                             double2* __restrict__ psi_new, uint32_t n_edges, uint32_t n_rows,
+                                             const uint32_t* __restrict__ blk_e0 = nullptr) {
+    // LOOKUP: the workgroup's edge offset comes from a table (cold scalar load) instead of blockIdx arithmetic
+    const uint32_t base = (LOOKUP ? blk_e0[blockIdx.x] : blockIdx.x * 256 * EPT) + threadIdx.x;
+    if (LOOKUP) n_edges = min(n_edges, blk_e0[blockIdx.x + 1]);  // ragged segment end, as the real kernel
     uint32_t l[EPT]; double2 a[EPT][2], m[EPT][2];
 #pragma unroll
     for (int j = 0; j < EPT; ++j) { uint32_t k = base + j * 256; l[j] = k < n_edges ? nbr[k] : 0; }
@@ -28,8 +32,9 @@ __global__ void __launch_bounds__(256) probe(const uint32_t* __restrict__ nbr, c
         }
     }
 }
-int main() {
-    const uint32_t N = 10000000, E = 100000000;
+int main(int argc, char** argv) {
+    const uint32_t N = 10000000;
+    uint32_t E = 100000000;
     std::vector<uint32_t> h(E);
     std::mt19937_64 rng(1);
     const uint32_t G = N / 4;
@@ -39,21 +44,45 @@ int main() {
         uint32_t tg = ((r & 0xffff) < 0.77 * 65536) ? g : uint32_t((g + 1 + ((r >> 16) % 3)) % 4);
         h[k] = tg * G + uint32_t((r >> 20) % G);
     }
+    if (argc > 1 && argv[1][0] && argv[1][0] != '-') {  // the real graph's neighbour array (uint32 binary dumped by tools/dump_nbr.py)
+        FILE* f = fopen(argv[1], "rb");
+        if (!f) { printf("cannot open %s\n", argv[1]); return 1; }
+        fseek(f, 0, SEEK_END); E = uint32_t(ftell(f) / 4); fseek(f, 0, SEEK_SET);
+        h.resize(E);
+        if (fread(h.data(), 4, E, f) != E) return 1;
+        fclose(f);
+        printf("using %u real neighbour indices from %s\n", E, argv[1]);
+    }
+    const uint32_t SEG = (argc > 2) ? uint32_t(atoi(argv[2])) : 512;  // edges per workgroup when looked up (real segments: ~505)
+    std::vector<uint32_t> hb((E + SEG - 1) / SEG + 1);
+    for (size_t b = 0; b < hb.size(); ++b) hb[b] = uint32_t(b * SEG);
+    printf("lookup segments of %u edges\n", SEG);
+    uint32_t* blk; CK(hipMalloc(&blk, hb.size() * 4)); CK(hipMemcpy(blk, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
     uint32_t* nbr; double2 *psi, *M, *psin;
     CK(hipMalloc(&nbr, size_t(E) * 4)); CK(hipMalloc(&psi, size_t(N) * 32)); CK(hipMalloc(&M, size_t(E) * 32)); CK(hipMalloc(&psin, size_t(N) * 32));
     CK(hipMemcpy(nbr, h.data(), size_t(E) * 4, hipMemcpyHostToDevice));
     CK(hipMemset(psi, 0, size_t(N) * 32)); CK(hipMemset(M, 0, size_t(E) * 32));
+    if (!(argc > 3 && argv[3][0] == 'z')) {  // random data by default: zero-filled tables read 9 % faster (pass 'z' to see it)
+        std::vector<double> r(1 << 24);
+        for (auto& x : r) x = double(rng() >> 11) / 9007199254740992.0;
+        for (size_t off = 0; off < size_t(N) * 4; off += r.size()) CK(hipMemcpy((double*)psi + off, r.data(), std::min(r.size(), size_t(N) * 4 - off) * 8, hipMemcpyHostToDevice));
+        for (size_t off = 0; off < size_t(E) * 4; off += r.size()) CK(hipMemcpy((double*)M + off, r.data(), std::min(r.size(), size_t(E) * 4 - off) * 8, hipMemcpyHostToDevice));
+        printf("tables filled with random data\n");
+    }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto run = [&](auto kern, int ept, const char* name) {
-        dim3 grid((E + 256 * ept - 1) / (256 * ept));
-        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, grid, dim3(256), 0, 0, nbr, psi, M, psin, E, N);
+        dim3 grid(ept == 2 ? uint32_t(hb.size() - 1) : (E + 256 * ept - 1) / (256 * ept));
+        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, grid, dim3(256), 0, 0, nbr, psi, M, psin, E, N, blk);
         CK(hipEventRecord(e0));
-        for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(kern, grid, dim3(256), 0, 0, nbr, psi, M, psin, E, N);
+        for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(kern, grid, dim3(256), 0, 0, nbr, psi, M, psin, E, N, blk);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         const double bytes = double(E) * (3 * 32 + 4) + double(N) * 40;
         printf("%s: %.3f ms/launch, algorithmic %.0f GB/s (%.1f%% of 8 TB/s)\n", name, ms / 10, bytes / (ms / 10 * 1e-3) / 1e9, bytes / (ms / 10 * 1e-3) / 8e12 * 100);
     };
-    run(probe<1>, 1, "probe EPT=1"); run(probe<2>, 2, "probe EPT=2"); run(probe<4>, 4, "probe EPT=4"); run(probe<8>, 8, "probe EPT=8");
+    run(probe<2>, 2, "probe EPT=2                     ");
+    run(probe<2, 1>, 2, "probe EPT=2 + bounds table lookup");
+    run(probe<1>, 1, "probe EPT=1                     ");
+    run(probe<4>, 4, "probe EPT=4                     ");
     return 0;
 }
