@@ -118,12 +118,20 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # SBMBP_REHEARSAL=1 (development aid, never the measured configuration): all ranks share cuda:0 and the
+    # collectives go over gloo through host memory, so the multi-process driver can run on a 1-GPU box
+    rehearsal = os.environ.get("SBMBP_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     sharded = world > 1 or args.force_sharded
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import sbm_bp_amd as S
     from sbm_bp_amd import synth
@@ -148,8 +156,8 @@ def main():
         E2_total = g.E2
         runner = bp
     else:
-        from sbm_bp_amd.distributed import ShardedBP
-        runner = ShardedBP.synthetic(N, Q, c, eps, gseed, dc=dc, seed=1234)
+        from sbm_bp_amd.distributed import ShardedBP, HostStagedComm
+        runner = ShardedBP.synthetic(N, Q, c, eps, gseed, dc=dc, seed=1234, comm=HostStagedComm() if rehearsal else None)
         E2_total = runner.E2_global
     setup_s = time.perf_counter() - t0
 
@@ -168,7 +176,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t1
     if sharded:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = runner.stats()
@@ -196,6 +204,8 @@ def main():
                          "traffic": pmc_traffic(args.workload, kname, world, E2_total, N, Q),
                          "kernel": kname, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
         }
+        if rehearsal:
+            out["rehearsal"] = "ranks share cuda:0, gloo collectives staged through the host: not a measurement"
         if sweeps_to_converge is not None:
             out["sweeps_to_converge"] = sweeps_to_converge
         if world == 1 and not args.no_cpu_baseline:

@@ -223,6 +223,33 @@ class TorchDistComm:
         self.dist.all_gather_into_tensor(outs[0], ins[0])
 
 
+class HostStagedComm(TorchDistComm):
+    """rehearsal / debugging only: the same calls over a backend without device collectives (gloo), every
+    buffer staged through host memory and every call blocking. RCCL refuses two ranks on one device; with
+    this comm several ranks may share one GPU, so the multi-process driver can be run on a 1-GPU box.
+    Never selected automatically."""
+
+    def exchange(self, recvs, sends, recv_counts, send_counts):
+        import torch
+        s = sends[0].cpu()  # blocks on the stream that packed the rows
+        r = torch.empty(tuple(recvs[0].shape), dtype=recvs[0].dtype)
+        self.dist.all_to_all_single(r, s, [int(x) for x in recv_counts[0]], [int(x) for x in send_counts[0]])
+        recvs[0].copy_(r)
+        return []
+
+    def all_reduce(self, tensors, op):
+        t = tensors[0].cpu()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX)
+        tensors[0].copy_(t)
+
+    def all_gather(self, outs, ins):
+        import torch
+        t = ins[0].cpu()
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t)
+        outs[0].copy_(torch.cat(parts))
+
+
 class LocalComm:
     """all shards live in this process (lock-step); collectives are tensor copies"""
 

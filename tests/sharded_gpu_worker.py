@@ -1,0 +1,52 @@
+"""worker of tests/test_gpu_sharded.py::test_three_processes_share_one_gpu (launched by torch.distributed.run):
+one HIP shard per process, all on cuda:0, collectives over gloo staged through the host (HostStagedComm)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE, os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+
+import oracle as orc  # noqa: E402
+from conftest import args_of, golden  # noqa: E402
+from sbm_bp_amd.distributed import HostStagedComm, ShardedBP  # noqa: E402
+
+
+def main():
+    out, name = sys.argv[1], sys.argv[2]
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    a = args_of(golden(name))
+    g = orc.Graph.from_edgelist(a["path"], a["N"])
+    bp = orc.OracleBP(g, a["Q"], a["dc"])
+    bp.init_messages(0, None, a["true_conf"], orc.Rng(a["seed"]))
+    cab, na = orc.param_from_direct(a["N"], a["Q"], a["pa"], a["cab_upper"])
+    psi0, msg0 = bp.get_state()
+    comm = HostStagedComm()
+    sb = ShardedBP.from_csr(g.row_ptr, g.nbr, a["Q"], a["dc"], comm)
+    assert sb.plans[0].n_chunks == 4  # the chunked exchange of the multi-rank path
+    p = sb.plans[0]
+    sb.init_messages_device(7, a["true_conf"])
+    sb.shards[0].set_state(psi0[p.row0:p.row0 + p.n_own], msg0[p.edge0:p.edge0 + p.n_edges])
+    sb.expand_bp_params(cab, na, a["beta"])
+    d3 = sb.sweep(3)
+    niter, exact = sb.converge(1e-12, 3000, 1.0, check_every=6)
+    ov = sb.compute_overlap()
+    fe = sb.compute_free_energy()
+    ent = sb.compute_entropy()
+    psi_local = sb.local_state()[0][0]
+    gathered = [None] * comm.world
+    dist.all_gather_object(gathered, psi_local)
+    if comm.rank == 0:
+        np.savez(out, d3=d3, niter=niter, exact=exact, overlap=ov, fe=fe, entropy=ent, psi=np.concatenate(gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -181,3 +181,34 @@ def test_sharded_learning_matches_single_engine_and_reference(S, orc):
     ref_cab = np.array(r["cab_final"]).reshape(2, 2)
     assert np.abs(np.sort(np.diag(res["cab"])) - np.sort(np.diag(ref_cab))).max() < 5e-2 * np.abs(ref_cab).max()
     assert abs(res["overlap"] - r["overlap"]) < 2e-2
+
+
+@pytest.mark.parametrize("name,world", [("q4_tight_seed0", 3)])
+def test_three_processes_share_one_gpu(orc, tmp_path, name, world):
+    """the multi-PROCESS driver with the HIP shard kernels: one shard per process, every process on cuda:0, the
+    collectives over gloo through host memory (RCCL refuses two ranks on one device, tools/nccl_dup_test.py).
+    Same calls, same order, same chunking as the RCCL path; result = the in-process run."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = tmp_path / "result.npz"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "tests", "sharded_gpu_worker.py"), str(out), name]
+    pr = subprocess.run(cmd, env=env, timeout=600, capture_output=True, text=True)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    res = np.load(out)
+    a, r, g, cab, na, psi0, msg0 = _problem(orc, name)
+    ref = _sharded(g, a, cab, na, psi0, msg0, world)
+    assert abs(ref.sweep(3) - float(res["d3"])) < 1e-15
+    niter, exact = ref.converge(1e-12, 3000, 1.0, check_every=6)
+    assert int(res["niter"]) == niter
+    psi = np.concatenate([s[0] for s in ref.local_state()])
+    assert np.abs(res["psi"] - psi).max() < 1e-14
+    assert abs(float(res["overlap"]) - ref.compute_overlap()) < 1e-14
+    assert abs(float(res["fe"]) - ref.compute_free_energy()) < 1e-13
+    assert abs(float(res["entropy"]) - ref.compute_entropy()) < 1e-13
+    # the reference's fixed point; shards evaluate the non-edge term by the order-4 moment series (bound of SURVEY A.4)
+    bound = a["N"] * (max(r["cab"]) / a["N"]) ** 5 / 10.0
+    assert abs(float(res["fe"]) - r["f"]) < max(2e-9, 2 * bound) * max(1.0, abs(r["f"]))
