@@ -2,8 +2,15 @@
 // each function replaces.
 #include "host_graph.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <thread>
@@ -25,6 +32,18 @@ template <typename F> static void parallel_ranges(uint64_t n, unsigned want, F f
     for (auto &x : th) x.join();
 }
 
+// SBMBP_HOST_TIMING=1: phase times of the host-side graph build on stderr (measurement aid)
+struct phase_timer {
+    bool on = std::getenv("SBMBP_HOST_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[sbmbp host] %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 static unsigned host_threads() {
     unsigned hc = std::thread::hardware_concurrency();
     return std::max(1u, std::min(hc ? hc : 1u, 32u));
@@ -36,31 +55,47 @@ static unsigned host_threads() {
 // The per-row work (sort, unique, compaction, reverse search) runs on host threads; the result does not
 // depend on the thread count.
 int graph_from_pairs(sbmbp_graph &g, const uint32_t *pairs, uint64_t n_pairs, uint32_t n_vertices) {
-    uint32_t n = n_vertices;
-    for (uint64_t e = 0; e < n_pairs; ++e) {  // the reference grows the adjacency to the largest id (:65-72)
-        uint32_t a = pairs[2 * e], b = pairs[2 * e + 1];
-        if (a == UINT32_MAX || b == UINT32_MAX) { set_error("vertex id 2^32-1 is reserved"); return SBMBP_ERR_ARG; }
-        if (a >= n) n = a + 1;
-        if (b >= n) n = b + 1;
-    }
-    if (2 * n_pairs >= (uint64_t(1) << 32)) { set_error("more than 2^32-1 directed edges"); return SBMBP_ERR_UNSUPPORTED; }
     const unsigned nt = host_threads();
-    std::vector<uint64_t> cnt(size_t(n) + 1, 0);
-    for (uint64_t e = 0; e < n_pairs; ++e) {
-        uint32_t a = pairs[2 * e], b = pairs[2 * e + 1];
-        cnt[a + 1]++;
-        if (a != b) cnt[b + 1]++;  // a self-loop is one set entry
-    }
-    for (uint32_t i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
-    std::vector<uint32_t> adj(cnt[n]);
-    {
-        std::vector<uint64_t> pos(cnt.begin(), cnt.end() - 1);
-        for (uint64_t e = 0; e < n_pairs; ++e) {
-            uint32_t a = pairs[2 * e], b = pairs[2 * e + 1];
-            adj[pos[a]++] = b;
-            if (a != b) adj[pos[b]++] = a;
+    phase_timer pt;
+    uint32_t n = n_vertices;
+    {   // the reference grows the adjacency to the largest id (:65-72)
+        std::vector<uint32_t> top(nt, 0);
+        std::vector<char> bad(nt, 0);
+        parallel_ranges(n_pairs, nt, [&](unsigned t, uint64_t lo, uint64_t hi) {
+            uint32_t m = 0;
+            for (uint64_t e = lo; e < hi; ++e) m = std::max(m, std::max(pairs[2 * e], pairs[2 * e + 1]));
+            if (hi > lo && m == UINT32_MAX) bad[t] = 1;
+            top[t] = hi > lo ? m + 1 : 0;
+        });
+        for (unsigned t = 0; t < nt; ++t) {
+            if (bad[t]) { set_error("vertex id 2^32-1 is reserved"); return SBMBP_ERR_ARG; }
+            n = std::max(n, top[t]);
         }
     }
+    if (2 * n_pairs >= (uint64_t(1) << 32)) { set_error("more than 2^32-1 directed edges"); return SBMBP_ERR_UNSUPPORTED; }
+    // bucket by source: the pair array is cut into one piece per thread; bucket sizes and slots are claimed
+    // with relaxed atomic adds (the order inside a bucket is arbitrary here and fixed by the sort below)
+    std::vector<uint32_t> fill(size_t(n), 0);
+    parallel_ranges(n_pairs, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
+        for (uint64_t e = lo; e < hi; ++e) {
+            uint32_t a = pairs[2 * e], b = pairs[2 * e + 1];
+            __atomic_fetch_add(&fill[a], 1u, __ATOMIC_RELAXED);
+            if (a != b) __atomic_fetch_add(&fill[b], 1u, __ATOMIC_RELAXED);  // a self-loop is one set entry
+        }
+    });
+    pt.lap("max id + bucket sizes");
+    std::vector<uint64_t> cnt(size_t(n) + 1, 0);
+    for (uint32_t i = 0; i < n; ++i) { cnt[i + 1] = cnt[i] + fill[i]; fill[i] = 0; }
+    std::vector<uint32_t> adj(cnt[n]);
+    parallel_ranges(n_pairs, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
+        for (uint64_t e = lo; e < hi; ++e) {
+            uint32_t a = pairs[2 * e], b = pairs[2 * e + 1];
+            adj[cnt[a] + __atomic_fetch_add(&fill[a], 1u, __ATOMIC_RELAXED)] = b;
+            if (a != b) adj[cnt[b] + __atomic_fetch_add(&fill[b], 1u, __ATOMIC_RELAXED)] = a;
+        }
+    });
+    std::vector<uint32_t>().swap(fill);
+    pt.lap("bucket fill");
     // sort + unique every row in place (front of its bucket), remember the unique length
     std::vector<uint32_t> ulen(n, 0);
     parallel_ranges(n, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
@@ -70,6 +105,7 @@ int graph_from_pairs(sbmbp_graph &g, const uint32_t *pairs, uint64_t n_pairs, ui
             ulen[i] = uint32_t(std::unique(b, e) - b);
         }
     });
+    pt.lap("row sort + unique");
     g.n = n;
     g.row_ptr.assign(size_t(n) + 1, 0);
     uint32_t maxdeg = 0;
@@ -80,6 +116,7 @@ int graph_from_pairs(sbmbp_graph &g, const uint32_t *pairs, uint64_t n_pairs, ui
         for (uint64_t i = lo; i < hi; ++i) std::copy(adj.data() + cnt[i], adj.data() + cnt[i] + ulen[i], g.nbr.data() + g.row_ptr[i]);
     });
     std::vector<uint32_t>().swap(adj);
+    pt.lap("compaction");
     g.rev.resize(g.nbr.size());
     parallel_ranges(n, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
         for (uint64_t i = lo; i < hi; ++i)
@@ -89,6 +126,7 @@ int graph_from_pairs(sbmbp_graph &g, const uint32_t *pairs, uint64_t n_pairs, ui
                 g.rev[k] = uint32_t(std::lower_bound(b, e, uint32_t(i)) - g.nbr.data());
             }
     });
+    pt.lap("reverse index");
     return SBMBP_OK;
 }
 
@@ -125,43 +163,96 @@ int graph_from_csr(sbmbp_graph &g, uint32_t n, uint64_t e2, const uint64_t *row_
 // load_edge_list (graph_utilities.cpp:42-58): one "a b" pair per line, whitespace separated,
 // 0-based ids. Deviations (documented): blank lines are skipped and a line without two
 // non-negative integers is an error (the reference silently re-pushes the previous pair, B14).
-int read_edgelist(const char *path, std::vector<uint32_t> &pairs) {
-    FILE *f = std::fopen(path, "rb");
-    if (!f) { set_error(std::string("cannot open edge list: ") + path); return SBMBP_ERR_IO; }
-    std::fseek(f, 0, SEEK_END);
-    long sz = std::ftell(f);
-    std::fseek(f, 0, SEEK_SET);
-    std::vector<char> buf(size_t(sz) + 1);
-    size_t got = std::fread(buf.data(), 1, size_t(sz), f);
-    std::fclose(f);
-    buf[got] = '\n';
-    pairs.clear();
-    pairs.reserve(got / 6);
-    const char *p = buf.data(), *end = buf.data() + got + 1;
-    uint64_t line = 1;
+namespace {
+struct parse_result {
+    std::vector<uint32_t> pairs;
+    uint64_t lines = 0;       // complete lines consumed before the error (or all of them)
+    int err = 0;              // 0 ok, 1 = not two integers, 2 = id too large, 3 = only one id
+};
+
+// parse [p, end): `end` is either the end of the file or just past a '\n' (chunks are cut at line starts)
+void parse_lines(const char *p, const char *end, parse_result &out) {
+    out.pairs.reserve(size_t(end - p) / 7);
     while (p < end) {
-        uint64_t v[2];
+        uint64_t v[2] = {0, 0};
         int nv = 0;
         while (p < end && *p != '\n') {
             if (*p == ' ' || *p == '\t' || *p == '\r') { ++p; continue; }
             if (*p < '0' || *p > '9') {
-                if (nv < 2) { set_error("edge list line " + std::to_string(line) + ": expected two non-negative integers"); return SBMBP_ERR_IO; }
+                if (nv < 2) { out.err = 1; return; }
                 while (p < end && *p != '\n') ++p;  // trailing columns (weights etc.) are ignored like the reference's stream reads
                 break;
             }
             uint64_t x = 0;
             while (p < end && *p >= '0' && *p <= '9') { x = x * 10 + uint64_t(*p - '0'); ++p; }
             if (nv < 2) {
-                if (x >= UINT32_MAX) { set_error("edge list line " + std::to_string(line) + ": id too large"); return SBMBP_ERR_IO; }
+                if (x >= UINT32_MAX) { out.err = 2; return; }
                 v[nv] = x;
             }
             ++nv;
         }
-        if (nv == 1) { set_error("edge list line " + std::to_string(line) + ": only one id"); return SBMBP_ERR_IO; }
-        if (nv >= 2) { pairs.push_back(uint32_t(v[0])); pairs.push_back(uint32_t(v[1])); }
+        if (nv == 1) { out.err = 3; return; }
+        if (nv >= 2) { out.pairs.push_back(uint32_t(v[0])); out.pairs.push_back(uint32_t(v[1])); }
         ++p;
-        ++line;
+        ++out.lines;
     }
+}
+}  // namespace
+
+// The file is mapped and cut at line starts into one piece per host thread; the pieces are parsed
+// concurrently and concatenated in file order (so the result, and the first error reported, are those
+// of a sequential read).
+int read_edgelist(const char *path, std::vector<uint32_t> &pairs) {
+    pairs.clear();
+    phase_timer pt;
+    int fd = ::open(path, O_RDONLY);
+    if (fd < 0) { set_error(std::string("cannot open edge list: ") + path); return SBMBP_ERR_IO; }
+    struct stat sb;
+    if (::fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { ::close(fd); set_error(std::string("cannot stat edge list: ") + path); return SBMBP_ERR_IO; }
+    const size_t sz = size_t(sb.st_size);
+    if (sz == 0) { ::close(fd); return SBMBP_OK; }
+    void *map = ::mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (map == MAP_FAILED) { set_error(std::string("cannot map edge list: ") + path); return SBMBP_ERR_IO; }
+    ::madvise(map, sz, MADV_SEQUENTIAL);
+    const char *base = static_cast<const char *>(map);
+    const unsigned nt = unsigned(std::max<size_t>(1, std::min<size_t>(host_threads(), sz / (size_t(4) << 20) + 1)));
+    std::vector<size_t> cut(nt + 1, sz);
+    cut[0] = 0;
+    for (unsigned t = 1; t < nt; ++t) {
+        size_t c = std::max(cut[t - 1], sz * t / nt);
+        while (c < sz && c > 0 && base[c - 1] != '\n') ++c;  // advance to the next line start
+        cut[t] = c;
+    }
+    std::vector<parse_result> res(nt);
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back([&, t] { parse_lines(base + cut[t], base + cut[t + 1], res[t]); });
+        parse_lines(base + cut[0], base + cut[1], res[0]);
+        for (auto &x : th) x.join();
+    }
+    ::munmap(map, sz);
+    uint64_t line = 1;
+    std::vector<size_t> off(nt + 1, 0);
+    for (unsigned t = 0; t < nt; ++t) {
+        if (res[t].err) {
+            const std::string where = "edge list line " + std::to_string(line + res[t].lines);
+            set_error(where + (res[t].err == 1 ? ": expected two non-negative integers" : res[t].err == 2 ? ": id too large" : ": only one id"));
+            return SBMBP_ERR_IO;
+        }
+        line += res[t].lines;
+        off[t + 1] = off[t] + res[t].pairs.size();
+    }
+    pt.lap("parse (mapped, parallel)");
+    if (nt == 1) { pairs.swap(res[0].pairs); return SBMBP_OK; }
+    pairs.resize(off[nt]);
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back([&, t] { if (!res[t].pairs.empty()) std::memcpy(pairs.data() + off[t], res[t].pairs.data(), res[t].pairs.size() * sizeof(uint32_t)); });
+        for (auto &x : th) x.join();
+    }
+    pt.lap("concatenate");
     return SBMBP_OK;
 }
 

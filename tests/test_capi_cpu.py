@@ -108,6 +108,27 @@ def test_edgelist_parser_errors(S, tmp_path):
     assert ei.value.code == -5  # documented deviation: the reference yields an empty graph
 
 
+def test_edgelist_parser_many_pieces(S, tmp_path):
+    """a file large enough to be cut into several pieces parsed concurrently: same pairs in file order, line number
+    of the first error counted across pieces, last line without a newline"""
+    rng = np.random.default_rng(3)
+    pairs = rng.integers(0, 200000, size=(1_200_000, 2), dtype=np.uint32)
+    p = tmp_path / "big.edgelist"
+    text = "\n".join("%d %d" % (a, b) for a, b in pairs)
+    assert len(text) > (12 << 20)
+    p.write_text(text)  # no trailing newline
+    g = S.load_edge_list(str(p), 200000)
+    ref = S.Graph.from_edges(pairs, 200000)
+    assert all(np.array_equal(x, y) for x, y in zip(g.csr(), ref.csr()))
+    lines = text.split("\n")
+    lines[1_100_000] = "17"  # line 1100001 holds one id
+    lines[1_150_000] = "x y"
+    p.write_text("\n".join(lines) + "\n")
+    with pytest.raises(S.SbmbpError) as ei:
+        S.load_edge_list(str(p), 200000)
+    assert "line 1100001" in str(ei.value) and "only one id" in str(ei.value)
+
+
 def test_param_constructors_equal_oracle_and_golden(S, orc):
     for name in ("c1_matched_tight_seed0", "q4_tight_seed0", "q4_epsc_default_seed0", "hub_dc0_tight_seed0"):
         gd = golden(name)
