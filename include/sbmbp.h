@@ -90,6 +90,10 @@ int sbmbp_set_stream(sbmbp_engine_t *e, void *hip_stream);
  * asserts). */
 int sbmbp_init_messages(sbmbp_engine_t *e, uint32_t flag, const int32_t *conf, const uint32_t *true_conf,
                         uint32_t seed, int conditional);
+/* the same initial state on the host only (no device, no engine): psi N*Q and msg_out E2*Q doubles in the
+ * layout of sbmbp_set_state; what sbmbp_init_messages uploads. */
+int sbmbp_host_init_state(const sbmbp_graph_t *g, uint32_t Q, uint32_t flag, const int32_t *conf, uint32_t seed,
+                          double *psi, double *msg_out);
 /* device-side random initialisation (counter-based generator) for large synthetic runs where the
  * sequential mt19937 fill would dominate; not stream-compatible with the reference. */
 int sbmbp_init_messages_device(sbmbp_engine_t *e, uint64_t seed, const uint32_t *true_conf);

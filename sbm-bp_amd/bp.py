@@ -54,6 +54,16 @@ class Graph:
                                              rev.ctypes.data_as(c_u32p)))
         return row_ptr, nbr, rev
 
+    def initial_state(self, Q, flag=0, conf=None, seed=0):
+        """the state init_messages (belief_propagation.cpp:101-217) produces from std::mt19937(seed), computed on the
+        host without an engine: (psi N x Q, msg_out E2 x Q)"""
+        psi = np.empty((self.N, Q), dtype=np.float64)
+        msg = np.empty((self.E2, Q), dtype=np.float64)
+        cf = None if conf is None else np.ascontiguousarray(conf, dtype=np.int32)
+        check(self._lib.sbmbp_host_init_state(self._h, Q, flag, None if cf is None else cf.ctypes.data_as(c_i32p), seed,
+                                              psi.ctypes.data_as(c_dp), msg.ctypes.data_as(c_dp)))
+        return psi, msg
+
     def __del__(self):
         try:
             self._lib.sbmbp_graph_destroy(self._h)

@@ -52,6 +52,7 @@ SYMBOLS = {
     "sbmbp_destroy": (None, [C.c_void_p]),
     "sbmbp_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sbmbp_init_messages": (C.c_int, [C.c_void_p, C.c_uint32, c_i32p, c_u32p, C.c_uint32, C.c_int]),
+    "sbmbp_host_init_state": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, c_i32p, C.c_uint32, c_dp, c_dp]),
     "sbmbp_init_messages_device": (C.c_int, [C.c_void_p, C.c_uint64, c_u32p]),
     "sbmbp_set_params": (C.c_int, [C.c_void_p, c_dp, c_u32p, C.c_double]),
     "sbmbp_get_params": (C.c_int, [C.c_void_p, c_dp, c_u32p]),

@@ -261,6 +261,15 @@ int main(int argc, char const *argv[]) {
     const float bp_conv_crit = float(num("bp_conv_crit", 5.0e-6)), learning_conv_crit = float(num("learning_conv_crit", 1.0e-6));
     const unsigned time_conv = unsigned(num("time_conv", 100));
 
+    // SBMBP_HOST_TIMING=1: wall time of each stage on stderr (measurement aid; stdout unchanged)
+    const bool stage_timing = std::getenv("SBMBP_HOST_TIMING") != nullptr;
+    auto stage_t = std::chrono::steady_clock::now();
+    auto stage = [&](const char *what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (stage_timing) std::fprintf(stderr, "[sbmbp cli ] %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - stage_t).count());
+        stage_t = now;
+    };
+
     // ---- graph (main.cpp:277-281) ---------------------------------------------------------------------
     sbmbp_graph_t *graph = nullptr;
     int rc = sbmbp_graph_load_edgelist(&graph, var_map.get("edge_list_path")[0].c_str(), N);
@@ -286,10 +295,12 @@ int main(int argc, char const *argv[]) {
     if (true_conf.size() != N) { std::clog << "bp: the true configuration needs " << N << " entries\n"; return 1; }
 
     if (mode != "infer" && mode != "learn") return 0;  // the reference silently does nothing (:361-365)
+    stage("read + index graph");
 
     sbmbp_engine_t *eng = nullptr;
     rc = sbmbp_create(&eng, graph, Q, deg_corr_flag, int(num("device", 0)));
     if (rc != SBMBP_OK) return fail(rc);
+    stage("create engine (device)");
 
     std::vector<int32_t> beliefs;  // :325-336
     if (var_map.count("beliefs_path")) {
@@ -304,6 +315,7 @@ int main(int argc, char const *argv[]) {
     rc = sbmbp_init_messages(eng, bp_messages_init_flag, beliefs.size() == N ? beliefs.data() : nullptr, true_conf.data(), seed,
                              mode == "learn" ? 0 : 1);  // bp_basic for learn, bp_conditional otherwise (:318-323)
     if (rc != SBMBP_OK) return fail(rc);
+    stage("initial state + upload");
 
     std::vector<double> cab_full(size_t(Q) * Q);
     std::vector<uint32_t> na(Q);
@@ -349,6 +361,7 @@ int main(int argc, char const *argv[]) {
         }
         std::clog << "overlap:" << res.overlap << "\n";
     }
+    stage(mode == "infer" ? "inference" : "learning");
     if (var_map.count("metrics_json")) {
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         sbmbp_stats st;

@@ -10,6 +10,7 @@
 #include <limits>
 #include <numeric>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "../../include/sbmbp.h"
@@ -891,10 +892,20 @@ int sbmbp_init_messages(sbmbp_engine_t *e, uint32_t flag, const int32_t *conf, c
     if (!e) return SBMBP_ERR_ARG;
     if (flag >= 4) { set_error("bp_messages_init_flag must be < 4"); return SBMBP_ERR_ARG; }  // assert at bp.cpp:106
     if (flag != 0 && !conf) { set_error("init flag != 0 needs a conf vector"); return SBMBP_ERR_ARG; }
-    std::vector<double> psi, msg;
-    init_state_host(e->N, e->h_row_ptr.data(), e->E2, e->Q, flag, conf, seed, psi, msg);
+    std::unique_ptr<double[]> psi(new double[size_t(e->N) * e->Q]), msg(new double[std::max<size_t>(1, e->E2 * e->Q)]);  // not zero-filled
+    init_state_host(e->N, e->h_row_ptr.data(), e->E2, e->Q, flag, conf, seed, psi.get(), msg.get());
     CHK(upload_labels(e, conf, true_conf, flag, conditional));
-    return sbmbp_set_state(e, psi.data(), msg.data());
+    return sbmbp_set_state(e, psi.get(), msg.get());
+}
+
+int sbmbp_host_init_state(const sbmbp_graph_t *g, uint32_t Q, uint32_t flag, const int32_t *conf, uint32_t seed, double *psi,
+                          double *msg_out) {
+    if (!g || !psi || (!msg_out && !g->nbr.empty()) || Q < 1 || Q > SBMBP_MAX_Q) return SBMBP_ERR_ARG;
+    if (flag >= 4) { set_error("bp_messages_init_flag must be < 4"); return SBMBP_ERR_ARG; }
+    if (flag != 0 && !conf) { set_error("init flag != 0 needs a conf vector"); return SBMBP_ERR_ARG; }
+    std::vector<uint32_t> rp32(g->row_ptr.begin(), g->row_ptr.end());
+    init_state_host(g->n, rp32.data(), g->nbr.size(), Q, flag, conf, seed, psi, msg_out);
+    return SBMBP_OK;
 }
 
 int sbmbp_init_messages_device(sbmbp_engine_t *e, uint64_t seed, const uint32_t *true_conf) {

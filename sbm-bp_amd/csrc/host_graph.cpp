@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -301,35 +302,128 @@ void param_from_direct(uint32_t N, uint32_t Q, const double *pa, const double *c
 // sequential fill. flag 1: planted rows get one-hot psi/messages, others random (:132-174).
 // flags 2/3 abort in the reference whenever a node is planted in group 1 (assert typo, B5);
 // here 2 = planted + 0.1 noise (normalised) and 3 = hard planted on all given rows.
-void init_state_host(uint32_t n, const uint32_t *row_ptr, uint64_t e2, uint32_t Q, uint32_t flag, const int32_t *conf,
-                     uint32_t seed, std::vector<double> &psi, std::vector<double> &msg) {
-    std::mt19937 engine(seed);
-    std::uniform_real_distribution<> random_real(0, 1);
-    psi.assign(size_t(n) * Q, 0.0);
-    msg.assign(e2 * Q, 0.0);
-    for (uint32_t i = 0; i < n; ++i) {
-        int32_t p = (flag == 0 || !conf) ? -1 : conf[i];
-        auto fill = [&](double *dst) {
-            if (p == -1 || flag == 0) {
-                double norm = 0.0;
-                for (uint32_t q = 0; q < Q; ++q) { dst[q] = random_real(engine); norm += dst[q]; }
-                for (uint32_t q = 0; q < Q; ++q) dst[q] /= norm;
-            } else if (flag == 2) {
-                const double noise = 0.1;
-                double norm = 0.0;
-                for (uint32_t q = 0; q < Q; ++q) {
-                    dst[q] = (int32_t(q) == p) ? noise + (1.0 - noise) * random_real(engine)
-                                               : random_real(engine) * (1.0 - noise);
-                    norm += dst[q];
-                }
-                for (uint32_t q = 0; q < Q; ++q) dst[q] /= norm;
-            } else {
-                for (uint32_t q = 0; q < Q; ++q) dst[q] = (int32_t(q) == p) ? 1.0 : 0.0;
-            }
-        };
-        fill(&psi[size_t(i) * Q]);
-        for (uint64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) fill(&msg[k * Q]);
+//
+// The draws are those of std::mt19937(seed) through std::uniform_real_distribution<double>(0, 1) (two
+// 32-bit words per double, generate_canonical<double, 53>), reproduced bit for bit by a block generator:
+// one thread produces the raw words of the next slab of vertices while the other host threads turn the
+// previous slab into normalised vectors (a vertex's position in the stream follows from a prefix sum of
+// 1 + degree over the vertices that draw at all).
+namespace {
+struct mt19937_words {  // MT19937 (Matsumoto & Nishimura 1998), same parameters and seeding as std::mt19937
+    uint32_t s[624];
+    unsigned pos = 624;
+    explicit mt19937_words(uint32_t seed) {
+        s[0] = seed;
+        for (uint32_t i = 1; i < 624; ++i) s[i] = 1812433253u * (s[i - 1] ^ (s[i - 1] >> 30)) + i;
     }
+    void twist() {
+        auto mix = [](uint32_t hi, uint32_t lo, uint32_t far) {
+            uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+            return far ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+        };
+        for (unsigned i = 0; i < 227; ++i) s[i] = mix(s[i], s[i + 1], s[i + 397]);
+        for (unsigned i = 227; i < 623; ++i) s[i] = mix(s[i], s[i + 1], s[i - 227]);
+        s[623] = mix(s[623], s[0], s[396]);
+        pos = 0;
+    }
+    static uint32_t temper(uint32_t y) {
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        return y ^ (y >> 18);
+    }
+    void fill(uint32_t *out, uint64_t count) {
+        while (count) {
+            if (pos == 624) twist();
+            const unsigned take = unsigned(std::min<uint64_t>(count, 624 - pos));
+            for (unsigned i = 0; i < take; ++i) out[i] = temper(s[pos + i]);
+            pos += take; out += take; count -= take;
+        }
+    }
+};
+
+// generate_canonical<double, 53> over a 32-bit engine: (w0 + w1 * 2^32) / 2^64, rounded as libstdc++ does
+inline double canonical(const uint32_t *w) {
+    double sum = double(w[0]);
+    sum += double(w[1]) * 4294967296.0;
+    double r = sum / 18446744073709551616.0;
+    return r >= 1.0 ? std::nextafter(1.0, 0.0) : r;
+}
+}  // namespace
+
+void init_state_host(uint32_t n, const uint32_t *row_ptr, uint64_t e2, uint32_t Q, uint32_t flag, const int32_t *conf,
+                     uint32_t seed, double *psi, double *msg) {
+    phase_timer pt;
+    (void)e2;
+    auto planted = [&](uint32_t i) -> int32_t { return (flag == 0 || !conf) ? -1 : conf[i]; };
+    auto draws = [&](uint32_t i) { return planted(i) == -1 || flag == 2; };  // hard-planted rows draw nothing
+    const uint64_t words_per_vec = 2 * uint64_t(Q);
+    const uint64_t slab_words = uint64_t(32) << 20;  // 128 MB of raw words per slab
+    // slabs of consecutive vertices with at most slab_words words each (a single huge row may exceed it)
+    std::vector<uint32_t> slab_start{0};
+    std::vector<uint64_t> slab_size;
+    {
+        uint64_t acc = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            uint64_t w = draws(i) ? (1 + uint64_t(row_ptr[i + 1] - row_ptr[i])) * words_per_vec : 0;
+            if (acc && acc + w > slab_words) { slab_start.push_back(i); slab_size.push_back(acc); acc = 0; }
+            acc += w;
+        }
+        slab_start.push_back(n);
+        slab_size.push_back(acc);
+    }
+    const size_t n_slabs = slab_size.size();
+    uint64_t biggest = 0;
+    for (uint64_t w : slab_size) biggest = std::max(biggest, w);
+    std::vector<uint32_t> raw[2];
+    raw[0].resize(biggest);
+    if (n_slabs > 1) raw[1].resize(biggest);
+    mt19937_words gen(seed);
+    const unsigned nt = host_threads();
+    auto consume = [&](size_t sl, const uint32_t *words) {
+        const uint32_t lo = slab_start[sl], hi = slab_start[sl + 1];
+        // word offset of every vertex of the slab: prefix sum, then the rows are independent
+        std::vector<uint64_t> off(size_t(hi - lo) + 1, 0);
+        for (uint32_t i = lo; i < hi; ++i)
+            off[i - lo + 1] = off[i - lo] + (draws(i) ? (1 + uint64_t(row_ptr[i + 1] - row_ptr[i])) * words_per_vec : 0);
+        parallel_ranges(hi - lo, nt, [&](unsigned, uint64_t a, uint64_t b) {
+            for (uint64_t r = a; r < b; ++r) {
+                const uint32_t i = lo + uint32_t(r);
+                const int32_t p = planted(i);
+                const uint32_t *w = words + off[r];
+                auto fill = [&](double *dst) {
+                    if (p == -1) {
+                        double norm = 0.0;
+                        for (uint32_t q = 0; q < Q; ++q) { dst[q] = canonical(w + 2 * q); norm += dst[q]; }
+                        for (uint32_t q = 0; q < Q; ++q) dst[q] /= norm;
+                        w += words_per_vec;
+                    } else if (flag == 2) {
+                        const double noise = 0.1;
+                        double norm = 0.0;
+                        for (uint32_t q = 0; q < Q; ++q) {
+                            const double u = canonical(w + 2 * q);
+                            dst[q] = (int32_t(q) == p) ? noise + (1.0 - noise) * u : u * (1.0 - noise);
+                            norm += dst[q];
+                        }
+                        for (uint32_t q = 0; q < Q; ++q) dst[q] /= norm;
+                        w += words_per_vec;
+                    } else {
+                        for (uint32_t q = 0; q < Q; ++q) dst[q] = (int32_t(q) == p) ? 1.0 : 0.0;
+                    }
+                };
+                fill(&psi[size_t(i) * Q]);
+                for (uint64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) fill(&msg[k * Q]);
+            }
+        });
+    };
+    gen.fill(raw[0].data(), slab_size[0]);
+    for (size_t sl = 0; sl < n_slabs; ++sl) {
+        std::thread producer;
+        if (sl + 1 < n_slabs) producer = std::thread([&, sl] { gen.fill(raw[(sl + 1) & 1].data(), slab_size[sl + 1]); });
+        consume(sl, raw[sl & 1].data());
+        if (producer.joinable()) producer.join();
+    }
+    pt.lap("initial state (mt19937)");
 }
 
 }  // namespace sbmbp

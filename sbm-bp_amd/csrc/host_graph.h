@@ -32,9 +32,10 @@ void param_from_epsilon_c(uint32_t N, uint32_t Q, double epsilon, double c, doub
 void param_from_direct(uint32_t N, uint32_t Q, const double *pa, const double *cab_upper, double *cab, uint32_t *na);
 
 // init_messages (belief_propagation.cpp:101-217) on the out-ordered layout; fills psi (N*Q) and
-// msg (E2*Q) from std::mt19937(seed) in the reference's draw order.
+// msg (E2*Q), both caller-allocated (need not be initialised), from std::mt19937(seed) in the reference's
+// draw order.
 void init_state_host(uint32_t n, const uint32_t *row_ptr, uint64_t e2, uint32_t Q, uint32_t flag, const int32_t *conf,
-                     uint32_t seed, std::vector<double> &psi, std::vector<double> &msg);
+                     uint32_t seed, double *psi, double *msg);
 
 }  // namespace sbmbp
 #endif

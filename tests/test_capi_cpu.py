@@ -129,6 +129,41 @@ def test_edgelist_parser_many_pieces(S, tmp_path):
     assert "line 1100001" in str(ei.value) and "only one id" in str(ei.value)
 
 
+@pytest.mark.parametrize("Q,flag", [(2, 0), (4, 0), (3, 1), (4, 2), (5, 3), (8, 0)])
+def test_host_initial_state_is_the_mt19937_stream(S, orc, Q, flag):
+    """sbmbp_host_init_state (block MT19937, rows filled concurrently) == the oracle's init_messages through
+    std::mt19937 + std::uniform_real_distribution (belief_propagation.cpp:101-217), bit for bit"""
+    rng = np.random.default_rng(Q * 10 + flag)
+    N = 3000
+    pairs = rng.integers(0, N, size=(9000, 2), dtype=np.uint32)
+    pairs = np.concatenate([pairs, np.array([[7, i] for i in range(8, 2500)], dtype=np.uint32)])  # one long row
+    g, og = S.Graph.from_edges(pairs, N), orc.Graph.from_edges(pairs, N)
+    conf = None
+    if flag:
+        conf = rng.integers(-1, Q, size=N).astype(np.int32)
+        conf[7] = -1 if flag == 1 else 1
+    for seed in (0, 5, 4294967295):
+        bp = orc.OracleBP(og, Q, 0)
+        bp.init_messages(flag, conf, np.zeros(N, dtype=np.uint32), orc.Rng(seed))
+        psi_o, msg_o = bp.get_state()
+        psi, msg = g.initial_state(Q, flag, conf, seed)
+        assert np.array_equal(psi, psi_o) and np.array_equal(msg, msg_o)
+
+
+def test_host_initial_state_across_slabs(S, orc):
+    """more than one slab of raw words (the generator thread runs ahead of the rows being filled)"""
+    N, Q = 1_500_000, 8
+    rng = np.random.default_rng(1)
+    pairs = rng.integers(0, N, size=(2_600_000, 2), dtype=np.uint32)
+    g, og = S.Graph.from_edges(pairs, N), orc.Graph.from_edges(pairs, N)
+    assert (N + g.E2) * 2 * Q > 3 * (32 << 20)
+    bp = orc.OracleBP(og, Q, 0)
+    bp.init_messages(0, None, np.zeros(N, dtype=np.uint32), orc.Rng(42))
+    psi_o, msg_o = bp.get_state()
+    psi, msg = g.initial_state(Q, 0, None, 42)
+    assert np.array_equal(psi, psi_o) and np.array_equal(msg, msg_o)
+
+
 def test_param_constructors_equal_oracle_and_golden(S, orc):
     for name in ("c1_matched_tight_seed0", "q4_tight_seed0", "q4_epsc_default_seed0", "hub_dc0_tight_seed0"):
         gd = golden(name)
