@@ -15,6 +15,8 @@ GPU, or on CPU with a stand-in backend).
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from sbm_bp_amd.plan import ShardPlan, partition_rows
@@ -295,7 +297,8 @@ class ShardedBP:
         if backend_factory is None:
             import torch
             dev = torch.cuda.current_device()
-            backend_factory = lambda plan: HipShardBackend(plan, Q, dc, dev)  # noqa: E731
+            compress = os.environ.get("SBMBP_HALO_COMPRESS", "1") != "0"  # Q-1 components on the wire (default) or all Q
+            backend_factory = lambda plan: HipShardBackend(plan, Q, dc, dev, compress=compress)  # noqa: E731
         self.shards = [backend_factory(p) for p in plans]
         self.N_global = plans[0].n_global
         self.E2_local = sum(p.n_edges for p in plans)
@@ -306,8 +309,8 @@ class ShardedBP:
     @classmethod
     def from_csr(cls, row_ptr, nbr, Q, dc, comm, backend_factory=None, n_chunks=None):
         bounds = partition_rows(row_ptr, comm.world)
-        if n_chunks is None:
-            n_chunks = 1 if comm.world == 1 else 4
+        if n_chunks is None:  # SBMBP_SHARD_CHUNKS: tuning knob for the compute/exchange overlap (default 4)
+            n_chunks = 1 if comm.world == 1 else max(1, int(os.environ.get("SBMBP_SHARD_CHUNKS", "4")))
         plans = [ShardPlan(row_ptr, nbr, bounds, r, n_chunks) for r in comm.local_ranks()]
         self = cls(plans, Q, dc, comm, backend_factory)
         self.E2_global = int(len(nbr))
