@@ -273,11 +273,11 @@ int read_conv_state(sbmbp_engine *e, conv_state *cs) {
 
 // exact criterion of the reference's converge(): max |m^{t+1} - m^t| over the two message buffers
 int message_diff(sbmbp_engine *e, double *out) {
-    const uint64_t n = e->E2 * e->Q;
+    const uint64_t n = e->E2;  // message records
     if (n == 0) { *out = 0.0; return SBMBP_OK; }
-    const uint32_t nb = uint32_t(std::min<uint64_t>(2048, (n / 2 + BLOCK - 1) / BLOCK + 1));
+    const uint32_t nb = uint32_t(std::min<uint64_t>(2048, (n + BLOCK - 1) / BLOCK));
     CHK(ensure_partials(e, size_t(nb) * 2));
-    hipLaunchKernelGGL(k_msg_diff, dim3(nb), dim3(BLOCK), 0, e->stream, e->d_M[0], e->d_M[1], n, e->d_partials);
+    hipLaunchKernelGGL(k_msg_diff, dim3(nb), dim3(BLOCK), 0, e->stream, e->d_M[0], e->d_M[1], n, int(e->Q) - 1, e->d_partials);
     hipLaunchKernelGGL(k_fold_stage, dim3(1), dim3(BLOCK), 0, e->stream, e->d_partials, nb, nb, 1, 1, 2u, e->d_stage);
     HIPCHK(hipGetLastError());
     double r[2];
@@ -800,8 +800,8 @@ int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint3
     TRY(dev_alloc(e, &e->d_hub_blk, hub_blk.size()));
     TRY(dev_alloc(e, &e->d_true, e->N));
     TRY(dev_alloc(e, &e->d_clamp, e->N));
-    TRY(dev_alloc(e, &e->d_M[0], std::max<uint64_t>(e->E2, 1) * Q));  // >= one Q-vector: the sweep's loads are branch-free
-    TRY(dev_alloc(e, &e->d_M[1], std::max<uint64_t>(e->E2, 1) * Q));
+    TRY(dev_alloc(e, &e->d_M[0], std::max<uint64_t>(e->E2, 1) * (Q - 1)));  // records of Q-1 components; >= one record: the sweep's loads are branch-free
+    TRY(dev_alloc(e, &e->d_M[1], std::max<uint64_t>(e->E2, 1) * (Q - 1)));
     TRY(dev_alloc(e, &e->d_psi[0], size_t(e->N) * Q));
     TRY(dev_alloc(e, &e->d_psi[1], size_t(e->N) * Q));
     TRY(dev_alloc(e, &e->d_P, 1));
@@ -912,12 +912,12 @@ int sbmbp_init_messages_device(sbmbp_engine_t *e, uint64_t seed, const uint32_t 
     if (!e) return SBMBP_ERR_ARG;
     CHK(upload_labels(e, nullptr, true_conf, 0, 0));
     hipLaunchKernelGGL(k_init_random, dim3((e->N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_psi[e->pcur], uint64_t(e->N),
-                       int(e->Q), seed, 0x1234567ull, uint64_t(e->row0));
+                       int(e->Q), int(e->Q), seed, 0x1234567ull, uint64_t(e->row0));
     if (e->E2)
         hipLaunchKernelGGL(k_init_random, dim3(uint32_t((e->E2 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, e->stream,
-                           e->d_M[e->cur], e->E2, int(e->Q), seed, 0xabcdef01ull, e->edge0);
+                           e->d_M[e->cur], e->E2, int(e->Q), int(e->Q) - 1, seed, 0xabcdef01ull, e->edge0);
     if (e->E2 && e->sharded)
-        HIPCHK(hipMemcpyAsync(e->d_M[e->cur ^ 1], e->d_M[e->cur], e->E2 * e->Q * 8, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->d_M[e->cur ^ 1], e->d_M[e->cur], e->E2 * (e->Q - 1) * 8, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     e->have_state = true;
@@ -938,12 +938,54 @@ int sbmbp_get_params(sbmbp_engine_t *e, double *cab, uint32_t *na) {
     return SBMBP_OK;
 }
 
+// The boundary speaks Q components per message; the device keeps records of Q-1 (kernels.h: msg_rec). The
+// conversion runs on the device, through a bounded staging buffer.
+static constexpr uint64_t STATE_SLAB = uint64_t(16) << 20;  // messages per staging pass
+
+static int upload_messages(sbmbp_engine *e, const double *msg_out, double *dst) {
+    const uint64_t slab = std::min<uint64_t>(e->E2, STATE_SLAB);
+    double *tmp = nullptr;
+    HIPCHK(hipMalloc(&tmp, slab * e->Q * 8));
+    for (uint64_t k0 = 0; k0 < e->E2; k0 += slab) {
+        const uint64_t n = std::min(slab, e->E2 - k0);
+        hipError_t err = hipMemcpyAsync(tmp, msg_out + k0 * e->Q, n * e->Q * 8, hipMemcpyHostToDevice, e->stream);
+        if (err == hipSuccess) {
+            hipLaunchKernelGGL(k_msgs_to_records, dim3(uint32_t((n * (e->Q - 1) + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, e->stream, tmp, n,
+                               int(e->Q), dst + k0 * (e->Q - 1));
+            err = hipGetLastError();
+        }
+        if (err != hipSuccess) { (void)hipFree(tmp); HIPCHK(err); }
+    }
+    hipError_t err = hipStreamSynchronize(e->stream);
+    (void)hipFree(tmp);
+    HIPCHK(err);
+    return SBMBP_OK;
+}
+
+static int download_messages(sbmbp_engine *e, const double *src, double *msg_out) {
+    const uint64_t slab = std::min<uint64_t>(e->E2, STATE_SLAB);
+    double *tmp = nullptr;
+    HIPCHK(hipMalloc(&tmp, slab * e->Q * 8));
+    for (uint64_t k0 = 0; k0 < e->E2; k0 += slab) {
+        const uint64_t n = std::min(slab, e->E2 - k0);
+        hipLaunchKernelGGL(k_records_to_msgs, dim3(uint32_t((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, e->stream, src + k0 * (e->Q - 1), n,
+                           int(e->Q), tmp);
+        hipError_t err = hipGetLastError();
+        if (err == hipSuccess) err = hipMemcpyAsync(msg_out + k0 * e->Q, tmp, n * e->Q * 8, hipMemcpyDeviceToHost, e->stream);
+        if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+        if (err != hipSuccess) { (void)hipFree(tmp); HIPCHK(err); }
+    }
+    (void)hipFree(tmp);
+    return SBMBP_OK;
+}
+
 int sbmbp_set_state(sbmbp_engine_t *e, const double *psi, const double *msg_out) {
     if (!e) return SBMBP_ERR_ARG;
     if (psi) HIPCHK(hipMemcpyAsync(e->d_psi[e->pcur], psi, size_t(e->N) * e->Q * 8, hipMemcpyHostToDevice, e->stream));
-    if (msg_out && e->E2) HIPCHK(hipMemcpyAsync(e->d_M[e->cur], msg_out, e->E2 * e->Q * 8, hipMemcpyHostToDevice, e->stream));
+    if (msg_out && e->E2) CHK(upload_messages(e, msg_out, e->d_M[e->cur]));
     // a sharded engine takes the declared state as (psi^0, m^-1): sweep 0 reads the buffer it then overwrites
-    if (msg_out && e->E2 && e->sharded) HIPCHK(hipMemcpyAsync(e->d_M[e->cur ^ 1], msg_out, e->E2 * e->Q * 8, hipMemcpyHostToDevice, e->stream));
+    if (msg_out && e->E2 && e->sharded)
+        HIPCHK(hipMemcpyAsync(e->d_M[e->cur ^ 1], e->d_M[e->cur], e->E2 * (e->Q - 1) * 8, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (psi && (msg_out || e->E2 == 0)) e->have_state = true;  // a graph without edges has no messages
     e->field_fresh = false;
@@ -953,8 +995,8 @@ int sbmbp_set_state(sbmbp_engine_t *e, const double *psi, const double *msg_out)
 int sbmbp_get_state(sbmbp_engine_t *e, double *psi, double *msg_out) {
     if (!e) return SBMBP_ERR_ARG;
     if (psi) HIPCHK(hipMemcpyAsync(psi, e->d_psi[e->pcur], size_t(e->N) * e->Q * 8, hipMemcpyDeviceToHost, e->stream));
-    if (msg_out && e->E2) HIPCHK(hipMemcpyAsync(msg_out, e->d_M[e->cur], e->E2 * e->Q * 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (msg_out && e->E2) CHK(download_messages(e, e->d_M[e->cur], msg_out));
     return SBMBP_OK;
 }
 int sbmbp_get_field(sbmbp_engine_t *e, double *h) {
@@ -1194,8 +1236,8 @@ int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *d, uint32_t
     TRY(dev_alloc(e, &e->d_hub_row, hub_row.size()));
     TRY(dev_alloc(e, &e->d_hub_blk, hub_blk.size()));
     TRY(dev_alloc(e, &e->d_true, e->N));
-    TRY(dev_alloc(e, &e->d_M[0], std::max<uint64_t>(e->E2, 1) * Q));  // >= one Q-vector: the sweep's loads are branch-free
-    TRY(dev_alloc(e, &e->d_M[1], std::max<uint64_t>(e->E2, 1) * Q));
+    TRY(dev_alloc(e, &e->d_M[0], std::max<uint64_t>(e->E2, 1) * (Q - 1)));  // records of Q-1 components; >= one record: the sweep's loads are branch-free
+    TRY(dev_alloc(e, &e->d_M[1], std::max<uint64_t>(e->E2, 1) * (Q - 1)));
     TRY(dev_alloc(e, &e->d_P, 1));
     e->hist_cap = 4096;
     TRY(dev_alloc(e, &e->d_hist, e->hist_cap));
@@ -1324,11 +1366,11 @@ int sbmbp_shard_finalize(sbmbp_engine_t *e, int mode, uint32_t n_rows) {
 
 int sbmbp_shard_msgdiff_partial(sbmbp_engine_t *e) {
     IS_SHARD(e);
-    const uint64_t n = e->E2 * e->Q;
+    const uint64_t n = e->E2;  // message records
     if (n == 0) { HIPCHK(hipMemsetAsync(e->d_red, 0, 8, e->stream)); return SBMBP_OK; }
-    const uint32_t nb = uint32_t(std::min<uint64_t>(2048, (n / 2 + BLOCK - 1) / BLOCK + 1));
+    const uint32_t nb = uint32_t(std::min<uint64_t>(2048, (n + BLOCK - 1) / BLOCK));
     CHK(ensure_partials(e, size_t(nb) * 2));
-    hipLaunchKernelGGL(k_msg_diff, dim3(nb), dim3(BLOCK), 0, e->stream, e->d_M[0], e->d_M[1], n, e->d_partials);
+    hipLaunchKernelGGL(k_msg_diff, dim3(nb), dim3(BLOCK), 0, e->stream, e->d_M[0], e->d_M[1], n, int(e->Q) - 1, e->d_partials);
     hipLaunchKernelGGL(k_fold_stage, dim3(1), dim3(BLOCK), 0, e->stream, e->d_partials, nb, nb, 1, 1, 2u, e->d_stage);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(e->d_red, e->d_stage + 1, 8, hipMemcpyDeviceToDevice, e->stream));
@@ -1386,7 +1428,7 @@ int sbmbp_shard_rearm(sbmbp_engine_t *e, double armed_crit) {
 
 // ---- reductions on shards: partial -> (caller all-reduces red) -> finish ----------------------------
 static int shard_materialize(sbmbp_engine_t *e) {
-    if (!e->d_Min) CHK(dev_alloc(e, &e->d_Min, e->E2 * e->Q));
+    if (!e->d_Min) CHK(dev_alloc(e, &e->d_Min, e->E2 * (e->Q - 1)));
     if (e->E2 == 0) return SBMBP_OK;
     const uint32_t nb = uint32_t(std::min<uint64_t>(4096, (e->E2 + BLOCK - 1) / BLOCK));
     DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_materialize_in<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_nbr, e->d_M[e->cur ^ 1],

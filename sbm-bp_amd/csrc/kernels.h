@@ -119,6 +119,64 @@ template <int Q> __device__ __forceinline__ void store_vec_stream(double *__rest
     store_vec<Q>(p, v);
 #endif
 }
+// ---- message records ------------------------------------------------------------------------------
+// A message is a distribution over Q groups, so only MC = Q-1 components are kept in HBM (record k at
+// M + k*MC); the last one is restored on load as max(0, 1 - sum) (a NaN stays a NaN). This removes 8 bytes
+// from every message read and write of the sweep. The marginal table keeps all Q components: its rows are
+// GATHERED, and a 32-byte row aligned to 32 bytes costs one fabric request where a 24-byte row would
+// straddle two in a quarter of the cases.
+template <int Q> struct msg_rec { static constexpr int MC = Q - 1; };
+template <int Q> __device__ __forceinline__ void finish_msg(double (&v)[Q]) {
+    double s = v[0];
+#pragma unroll
+    for (int q = 1; q < Q - 1; ++q) s += v[q];
+    const double r = 1.0 - s;
+    v[Q - 1] = r < 0.0 ? 0.0 : r;
+}
+template <int Q> __device__ __forceinline__ void load_msg(const double *__restrict__ M, size_t k, double (&v)[Q]) {
+    constexpr int MC = msg_rec<Q>::MC;
+    const double *p = M + k * MC;
+    if (MC % 2 == 0) {
+        const double2 *p2 = reinterpret_cast<const double2 *>(p);
+#pragma unroll
+        for (int j = 0; j < MC / 2; ++j) { double2 t = p2[j]; v[2 * j] = t.x; v[2 * j + 1] = t.y; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < MC; ++q) v[q] = p[q];
+    }
+    finish_msg<Q>(v);
+}
+template <int Q> __device__ __forceinline__ void store_msg(double *__restrict__ M, size_t k, const double (&v)[Q]) {
+    constexpr int MC = msg_rec<Q>::MC;
+    double *p = M + k * MC;
+    if (MC % 2 == 0) {
+        double2 *p2 = reinterpret_cast<double2 *>(p);
+#pragma unroll
+        for (int j = 0; j < MC / 2; ++j) p2[j] = make_double2(v[2 * j], v[2 * j + 1]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < MC; ++q) p[q] = v[q];
+    }
+}
+template <int Q> __device__ __forceinline__ void load_msg_stream(const double *__restrict__ M, size_t k, double (&v)[Q]) {
+#if SBMBP_NT & 1
+    constexpr int MC = msg_rec<Q>::MC;
+#pragma unroll
+    for (int q = 0; q < MC; ++q) v[q] = __builtin_nontemporal_load(M + k * MC + q);
+    finish_msg<Q>(v);
+#else
+    load_msg<Q>(M, k, v);
+#endif
+}
+template <int Q> __device__ __forceinline__ void store_msg_stream(double *__restrict__ M, size_t k, const double (&v)[Q]) {
+#if SBMBP_NT & 2
+    constexpr int MC = msg_rec<Q>::MC;
+#pragma unroll
+    for (int q = 0; q < MC; ++q) __builtin_nontemporal_store(v[q], M + k * MC + q);
+#else
+    store_msg<Q>(M, k, v);
+#endif
+}
 __device__ __forceinline__ uint32_t load_idx_stream(const uint32_t *__restrict__ p) {
 #if SBMBP_NT & 1
     return __builtin_nontemporal_load(p);
@@ -307,13 +365,13 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
 #pragma unroll
     for (int j = 0; j < EPT; ++j) rk[j] = load_idx_stream(rev + kk[j]);
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) load_vec_stream<Q>(Mold + size_t(kk[j]) * Q, mo[j]);
+    for (int j = 0; j < EPT; ++j) load_msg_stream<Q>(Mold, kk[j], mo[j]);
     uint32_t rpv[RPT];
 #pragma unroll
     for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; rpv[t] = row_ptr[r0 + uint32_t(r < nrows ? r : nrows)]; }
     double mi[EPT][Q];
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) load_vec<Q>(Mold + size_t(rk[j]) * Q, mi[j]);
+    for (int j = 0; j < EPT; ++j) load_msg<Q>(Mold, rk[j], mi[j]);
     if (tid == 0) sbig = 0;
 #pragma unroll
     for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; if (r <= nrows) srp[r] = rpv[t] - e0; }
@@ -436,7 +494,7 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
                     out[q] = damp * nv + (1.0 - damp) * mo[j][q];
                 }
             }
-            store_vec_stream<Q>(Mnew + size_t(e0 + le) * Q, out);
+            store_msg_stream<Q>(Mnew, size_t(e0 + le), out);
         }
     }
     block_reduce_store<Q, FWAVES>(Sacc, md, sred, partials + size_t(blockIdx.x) * (Q + 1));
@@ -499,7 +557,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
 #pragma unroll
     for (int j = 0; j < EPT; ++j) nl[j] = load_idx_stream(nbr + kk[j]);
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) load_vec_stream<Q>(Mio + size_t(kk[j]) * Q, mo[j]);
+    for (int j = 0; j < EPT; ++j) load_msg_stream<Q>(Mio, kk[j], mo[j]);
     uint32_t rpv[RPT];
 #pragma unroll
     for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; rpv[t] = row_ptr[r0 + uint32_t(r < nrows ? r : nrows)]; }
@@ -593,7 +651,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
                 out[q] = cav[q] * inv;
                 md = nanmax(md, fabs(mo[j][q] - out[q]));
             }
-            store_vec_stream<Q>(Mio + size_t(e0 + le) * Q, out);
+            store_msg_stream<Q>(Mio, size_t(e0 + le), out);
         }
     }
     block_reduce_store<Q, FWAVES>(Sacc, md, sred, partials + size_t(blockIdx.x) * (Q + 1));
@@ -625,7 +683,7 @@ k_sweep_psi_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict
     auto incoming_field = [&](uint32_t le, double (&mo)[Q], double (&b)[Q]) {
         double pl[Q], bo[Q], inc[Q];
         load_vec<Q>(psi_old + size_t(nbr[e0 + le]) * Q, pl);
-        load_vec<Q>(Mio + size_t(e0 + le) * Q, mo);
+        load_msg<Q>(Mio, size_t(e0 + le), mo);
         edge_field<Q, false>(P, mo, 0.0, bo);
         double tot = 0.0;
 #pragma unroll
@@ -679,7 +737,7 @@ k_sweep_psi_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict
             out[q] = cav[q] * ci;
             md = nanmax(md, fabs(mo[q] - out[q]));
         }
-        store_vec<Q>(Mio + size_t(e0 + le) * Q, out);
+        store_msg<Q>(Mio, size_t(e0 + le), out);
     }
     block_reduce_store<Q>(Sacc, md, sred, partials + size_t(hub_blk[blockIdx.x]) * (Q + 1));
 }
@@ -711,19 +769,25 @@ k_unpack_rows(const double *__restrict__ in, uint32_t n, int Q, int ncomp, doubl
     if (ncomp < Q) table[row * Q + (Q - 1)] = fmax(0.0, 1.0 - s);
 }
 
-// exact 1-step criterion of converge (bp.cpp:1059-1063): max over all message entries |a - b|
+// exact 1-step criterion of converge (bp.cpp:1059-1063): max over all message entries |a - b|, the implied
+// last component of every record included
 __global__ void __launch_bounds__(BLOCK)
-k_msg_diff(const double *__restrict__ a, const double *__restrict__ b, uint64_t n, double *__restrict__ partials) {
+k_msg_diff(const double *__restrict__ a, const double *__restrict__ b, uint64_t n_msg, int mc, double *__restrict__ partials) {
     __shared__ double sred[4 * 2];
     double md = 0.0;
-    const uint64_t n2 = n / 2;
-    const double2 *a2 = reinterpret_cast<const double2 *>(a), *b2 = reinterpret_cast<const double2 *>(b);
-    for (uint64_t i = uint64_t(blockIdx.x) * BLOCK + threadIdx.x; i < n2; i += uint64_t(gridDim.x) * BLOCK) {
-        const double2 x = a2[i], y = b2[i];
-        md = nanmax(md, fabs(x.x - y.x));
-        md = nanmax(md, fabs(x.y - y.y));
+    for (uint64_t k = uint64_t(blockIdx.x) * BLOCK + threadIdx.x; k < n_msg; k += uint64_t(gridDim.x) * BLOCK) {
+        double sa = 0.0, sb = 0.0;
+        for (int q = 0; q < mc; ++q) {
+            const double x = a[k * mc + q], y = b[k * mc + q];
+            md = nanmax(md, fabs(x - y));
+            sa += x;
+            sb += y;
+        }
+        double ra = 1.0 - sa, rb = 1.0 - sb;
+        ra = ra < 0.0 ? 0.0 : ra;
+        rb = rb < 0.0 ? 0.0 : rb;
+        md = nanmax(md, fabs(ra - rb));
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) md = nanmax(md, fabs(a[n - 1] - b[n - 1]));
     double dummy[1] = {0.0};
     block_reduce_store<1, 4>(dummy, md, sred, partials + size_t(blockIdx.x) * 2);
 }
@@ -755,8 +819,8 @@ k_sweep_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ r
     if (clamped) {
         for (uint32_t le = tid; le < d; le += BLOCK) {
             double m[Q];
-            load_vec<Q>(Mold + size_t(e0 + le) * Q, m);
-            store_vec<Q>(Mnew + size_t(e0 + le) * Q, m);
+            load_msg<Q>(Mold, size_t(e0 + le), m);
+            store_msg<Q>(Mnew, size_t(e0 + le), m);
         }
         if (tid == 0) {
             double pv[Q];
@@ -772,7 +836,7 @@ k_sweep_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ r
         for (int q = 0; q < Q; ++q) A[q] = 1.0;
         for (uint32_t le = tid; le < d; le += BLOCK) {
             double m[Q], b[Q];
-            load_vec<Q>(Mold + size_t(rev[e0 + le]) * Q, m);
+            load_msg<Q>(Mold, rev[e0 + le], m);
             double didl = 0.0;
             if (DC2) { const uint32_t l = nbr[e0 + le]; didl = di * double(row_ptr[l + 1] - row_ptr[l]); }
             edge_field<Q, DC2>(P, m, didl, b);
@@ -807,8 +871,8 @@ k_sweep_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ r
         }
         for (uint32_t le = tid; le < d; le += BLOCK) {
             double m[Q], b[Q], mo[Q], out[Q];
-            load_vec<Q>(Mold + size_t(rev[e0 + le]) * Q, m);
-            load_vec<Q>(Mold + size_t(e0 + le) * Q, mo);
+            load_msg<Q>(Mold, rev[e0 + le], m);
+            load_msg<Q>(Mold, size_t(e0 + le), mo);
             double didl = 0.0;
             if (DC2) { const uint32_t l = nbr[e0 + le]; didl = di * double(row_ptr[l + 1] - row_ptr[l]); }
             edge_field<Q, DC2>(P, m, didl, b);
@@ -822,7 +886,7 @@ k_sweep_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ r
                 md = nanmax(md, fabs(mo[q] - nv));
                 out[q] = damp * nv + (1.0 - damp) * mo[q];
             }
-            store_vec<Q>(Mnew + size_t(e0 + le) * Q, out);
+            store_msg<Q>(Mnew, size_t(e0 + le), out);
         }
     }
     block_reduce_store<Q>(Sacc, md, sred, partials + size_t(hub_blk[blockIdx.x]) * (Q + 1));
@@ -966,8 +1030,8 @@ k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
             const int le = j * FTPB + tid;
             if (le < ne) {
                 double mi[Q], mo[Q], b[Q];
-                load_vec<Q>(Min ? Min + size_t(e0 + le) * Q : M + size_t(rev[e0 + le]) * Q, mi);
-                load_vec<Q>(M + size_t(e0 + le) * Q, mo);
+                load_msg<Q>(Min ? Min : M, Min ? size_t(e0 + le) : size_t(rev[e0 + le]), mi);
+                load_msg<Q>(M, size_t(e0 + le), mo);
                 double didl = 0.0;
                 if (DC2) {
                     const int r = srow[le];
@@ -1051,8 +1115,8 @@ k_fe_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev,
     for (int q = 0; q < Q; ++q) { A[q] = 1.0; C[q] = 1.0; }
     for (uint32_t le = tid; le < d; le += BLOCK) {
         double mi[Q], mo[Q], b[Q];
-        load_vec<Q>(Min ? Min + size_t(e0 + le) * Q : M + size_t(rev[e0 + le]) * Q, mi);
-        load_vec<Q>(M + size_t(e0 + le) * Q, mo);
+        load_msg<Q>(Min ? Min : M, Min ? size_t(e0 + le) : size_t(rev[e0 + le]), mi);
+        load_msg<Q>(M, size_t(e0 + le), mo);
         double didl = 0.0;
         if (DC2) { const uint32_t l = nbr[e0 + le]; didl = di * double(row_ptr[l + 1] - row_ptr[l]); }
         edge_field<Q, DC2>(P, mi, didl, b);
@@ -1369,8 +1433,8 @@ k_em_edges(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
     for (int t = 0; t < T; ++t) acc[t] = 0.0;
     for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < n_edges; k += gridDim.x * BLOCK) {
         double mi[Q], mo[Q];
-        load_vec<Q>(Min ? Min + size_t(k) * Q : M + size_t(rev[k]) * Q, mi);
-        load_vec<Q>(M + size_t(k) * Q, mo);
+        load_msg<Q>(Min ? Min : M, Min ? size_t(k) : size_t(rev[k]), mi);
+        load_msg<Q>(M, size_t(k), mo);
         double didl = 0.0;
         if (DC2) {
             const uint32_t i = src[k], l = nbr[k];
@@ -1406,7 +1470,7 @@ k_materialize_in(const uint32_t *__restrict__ nbr, const double *__restrict__ Mp
     for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < n_edges; k += gridDim.x * BLOCK) {
         double pl[Q], mo[Q], bo[Q], inc[Q];
         load_vec<Q>(psi + size_t(nbr[k]) * Q, pl);
-        load_vec<Q>(Mprev + size_t(k) * Q, mo);
+        load_msg<Q>(Mprev, size_t(k), mo);
         edge_field<Q, false>(P, mo, 0.0, bo);
         double tot = 0.0;
 #pragma unroll
@@ -1414,7 +1478,7 @@ k_materialize_in(const uint32_t *__restrict__ nbr, const double *__restrict__ Mp
         const double inv = 1.0 / tot;
 #pragma unroll
         for (int s = 0; s < Q; ++s) inc[s] *= inv;
-        store_vec<Q>(Min + size_t(k) * Q, inc);
+        store_msg<Q>(Min, size_t(k), inc);
     }
 }
 
@@ -1469,13 +1533,33 @@ __device__ __forceinline__ double u01(uint64_t seed, uint64_t idx) {
     z ^= z >> 31;
     return (double(z >> 11) + 0.5) * (1.0 / 9007199254740992.0);
 }
+// ncomp = Q for marginal rows, Q-1 for message records (the last component is implied)
 __global__ void __launch_bounds__(BLOCK)
-k_init_random(double *__restrict__ v, uint64_t n_vec, int Q, uint64_t seed, uint64_t salt, uint64_t index0) {
+k_init_random(double *__restrict__ v, uint64_t n_vec, int Q, int ncomp, uint64_t seed, uint64_t salt, uint64_t index0) {
     const uint64_t i = uint64_t(blockIdx.x) * BLOCK + threadIdx.x;
     if (i >= n_vec) return;
     double t[QMAX], norm = 0.0;
     for (int q = 0; q < Q; ++q) { t[q] = u01(seed ^ salt, (index0 + i) * uint64_t(Q) + q); norm += t[q]; }
-    for (int q = 0; q < Q; ++q) v[i * Q + q] = t[q] / norm;
+    for (int q = 0; q < ncomp; ++q) v[i * ncomp + q] = t[q] / norm;
+}
+
+// host layout (Q components per message, sbmbp_set_state / sbmbp_get_state) <-> message records (Q-1 components)
+__global__ void __launch_bounds__(BLOCK)
+k_msgs_to_records(const double *__restrict__ full, uint64_t n_msg, int Q, double *__restrict__ rec) {
+    const uint64_t t = uint64_t(blockIdx.x) * BLOCK + threadIdx.x;
+    const int mc = Q - 1;
+    if (t >= n_msg * mc) return;
+    rec[t] = full[(t / mc) * Q + (t % mc)];
+}
+__global__ void __launch_bounds__(BLOCK)
+k_records_to_msgs(const double *__restrict__ rec, uint64_t n_msg, int Q, double *__restrict__ full) {
+    const uint64_t k = uint64_t(blockIdx.x) * BLOCK + threadIdx.x;
+    if (k >= n_msg) return;
+    const int mc = Q - 1;
+    double s = 0.0;
+    for (int q = 0; q < mc; ++q) { const double v = rec[k * mc + q]; full[k * Q + q] = v; s += v; }
+    const double r = 1.0 - s;
+    full[k * Q + mc] = r < 0.0 ? 0.0 : r;
 }
 
 }  // namespace sbmbp

@@ -54,7 +54,10 @@ def test_initial_state_is_the_reference_rng_stream(S, orc, name):
     _, obp, _ = oracle_from(orc, a)
     psi, msg = bp.get_state()
     opsi, omsg = obp.get_state()
-    assert (psi == opsi).all() and (msg == omsg).all()  # bit-exact: same mt19937 draws, same fill order
+    # bit-exact: same mt19937 draws, same fill order. The device keeps Q-1 components of every message and
+    # restores the last as 1 - sum, so that one column comes back within a few ulp instead of bit-exact
+    assert (psi == opsi).all() and (msg[:, :-1] == omsg[:, :-1]).all()
+    assert np.abs(msg[:, -1] - omsg[:, -1]).max() < 5e-16
 
 
 @pytest.mark.parametrize("name", TIGHT + ["hub_dc0_tight_seed0"])

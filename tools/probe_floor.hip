@@ -32,6 +32,68 @@ __global__ void __launch_bounds__(256) probe(const uint32_t* __restrict__ nbr, c
         }
     }
 }
+// own message kept as Q-1 = 3 components (24-byte records, contiguous per wave): -8 B read, -8 B write per edge
+template <int EPT>
+__global__ void __launch_bounds__(256) probe3(const uint32_t* __restrict__ nbr, const double2* __restrict__ psi, double2* __restrict__ M2,
+                                              double2* __restrict__ psi_new, uint32_t n_edges, uint32_t n_rows,
+                                              const uint32_t* __restrict__ blk_e0 = nullptr) {
+    double* __restrict__ M = reinterpret_cast<double*>(M2);
+    const uint32_t base = blk_e0[blockIdx.x] + threadIdx.x;
+    n_edges = min(n_edges, blk_e0[blockIdx.x + 1]);
+    uint32_t l[EPT]; double2 a[EPT][2]; double m[EPT][3];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) { uint32_t k = base + j * 256; l[j] = k < n_edges ? nbr[k] : 0; }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) { a[j][0] = psi[size_t(l[j]) * 2]; a[j][1] = psi[size_t(l[j]) * 2 + 1]; }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) { uint32_t k = base + j * 256; if (k < n_edges) { m[j][0] = M[size_t(k) * 3]; m[j][1] = M[size_t(k) * 3 + 1]; m[j][2] = M[size_t(k) * 3 + 2]; } }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        uint32_t k = base + j * 256;
+        if (k < n_edges) {
+            M[size_t(k) * 3] = m[j][0] * 0.5 + a[j][0].x * 0.5;
+            M[size_t(k) * 3 + 1] = m[j][1] * 0.5 + a[j][0].y * 0.5;
+            M[size_t(k) * 3 + 2] = m[j][2] * 0.5 + a[j][1].x * 0.5 + a[j][1].y * 1e-9;
+            if (k % 10 == 0 && k / 10 < n_rows) { psi_new[size_t(k / 10) * 2] = a[j][0]; psi_new[size_t(k / 10) * 2 + 1] = a[j][1]; }
+        }
+    }
+}
+// same, records staged through LDS so that global accesses are whole 16-byte lanes over the workgroup's contiguous span
+template <int EPT>
+__global__ void __launch_bounds__(256) probe3_lds(const uint32_t* __restrict__ nbr, const double2* __restrict__ psi, double2* __restrict__ M2,
+                                                  double2* __restrict__ psi_new, uint32_t n_edges, uint32_t n_rows,
+                                                  const uint32_t* __restrict__ blk_e0 = nullptr) {
+    __shared__ double stage[256 * EPT * 3];
+    double* __restrict__ M = reinterpret_cast<double*>(M2);
+    const uint32_t e0 = blk_e0[blockIdx.x];
+    const uint32_t e1 = min(n_edges, blk_e0[blockIdx.x + 1]);
+    const uint32_t cnt = e1 - e0, nd = cnt * 3;
+    uint32_t l[EPT]; double2 a[EPT][2];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) { uint32_t k = threadIdx.x + j * 256; l[j] = k < cnt ? nbr[e0 + k] : 0; }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) { a[j][0] = psi[size_t(l[j]) * 2]; a[j][1] = psi[size_t(l[j]) * 2 + 1]; }
+    const double* src = M + size_t(e0) * 3;
+    for (uint32_t i = threadIdx.x; i < nd; i += 256) stage[i] = src[i];
+    __syncthreads();
+    double o[EPT][3];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        uint32_t k = threadIdx.x + j * 256;
+        if (k < cnt) {
+            o[j][0] = stage[k * 3] * 0.5 + a[j][0].x * 0.5;
+            o[j][1] = stage[k * 3 + 1] * 0.5 + a[j][0].y * 0.5;
+            o[j][2] = stage[k * 3 + 2] * 0.5 + a[j][1].x * 0.5 + a[j][1].y * 1e-9;
+            if ((e0 + k) % 10 == 0 && (e0 + k) / 10 < n_rows) { psi_new[size_t((e0 + k) / 10) * 2] = a[j][0]; psi_new[size_t((e0 + k) / 10) * 2 + 1] = a[j][1]; }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) { uint32_t k = threadIdx.x + j * 256; if (k < cnt) { stage[k * 3] = o[j][0]; stage[k * 3 + 1] = o[j][1]; stage[k * 3 + 2] = o[j][2]; } }
+    __syncthreads();
+    double* dst = M + size_t(e0) * 3;
+    for (uint32_t i = threadIdx.x; i < nd; i += 256) dst[i] = stage[i];
+}
 int main(int argc, char** argv) {
     const uint32_t N = 10000000;
     uint32_t E = 100000000;
@@ -82,6 +144,8 @@ int main(int argc, char** argv) {
     };
     run(probe<2>, 2, "probe EPT=2                     ");
     run(probe<2, 1>, 2, "probe EPT=2 + bounds table lookup");
+    run(probe3<2>, 2, "probe EPT=2, 24-B own messages   ");
+    run(probe3_lds<2>, 2, "probe EPT=2, 24-B msgs via LDS   ");
     run(probe<1>, 1, "probe EPT=1                     ");
     run(probe<4>, 4, "probe EPT=4                     ");
     return 0;
