@@ -90,7 +90,7 @@ def pmc_traffic(workload, kernel, n_gpus, E2, N, Q):
             continue
         if d.get("kernel") == kernel and d.get("workload", "").startswith(workload + " "):
             c = d["counters"]
-            stream_reads = E2 * (8.0 * Q + 4.0) + N * 4.0  # own old message + index per edge, row offsets
+            stream_reads = E2 * (8.0 * (Q - 1) + 4.0) + N * 4.0  # own old message record (Q-1 components) + index per edge, row offsets
             return c["FETCH_SIZE"]["per_launch_mean"] * 1024.0 + 0.5 * stream_reads + c["WRITE_SIZE"]["per_launch_mean"] * 1024.0
     return None
 

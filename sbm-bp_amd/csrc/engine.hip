@@ -52,6 +52,8 @@ struct sbmbp_engine {
     uint32_t *d_blk_row = nullptr, *d_blk_e0 = nullptr, *d_hub_row = nullptr, *d_hub_blk = nullptr, *d_true = nullptr;
     int32_t *d_clamp = nullptr;
     uint32_t n_blk = 0, n_hub = 0;
+    hipStream_t hub_stream = nullptr;  // hub rows (one workgroup each, latency-bound) run beside the frame kernel
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // state in HBM
     double *d_M[2] = {nullptr, nullptr};
     int cur = 0;
@@ -200,6 +202,34 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form) {
     const double *psi_old = e->d_psi[pc];
     double *psi_new = e->d_psi[pc ^ 1];
     const int32_t *clamp = e->has_clamp ? e->d_clamp : nullptr;
+    // hub rows first, on their own stream: a few hundred long-running workgroups that overlap with the frame kernel
+    // (disjoint rows and edges; both only read psi_old and the parameter block)
+    if (e->n_hub) {
+        if (!e->hub_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&e->hub_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+        }
+        hipStream_t hs = e->hub_stream;
+        HIPCHK(hipEventRecord(e->ev_fork, e->stream));
+        HIPCHK(hipStreamWaitEvent(hs, e->ev_fork, 0));
+        if (e->n_hub && psi_form) {
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi_hub<QQ>), dim3(e->n_hub), dim3(BLOCK), 0, hs, e->d_row_ptr,
+                                                e->d_nbr, Mnew, psi_old, psi_new, e->d_hub_row, e->d_hub_blk, e->d_P,
+                                                int(e->dc), e->d_partials));
+        } else if (e->n_hub) {
+            if (e->dc == 2) {
+                DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, hs,
+                                                    e->d_row_ptr, e->d_rev, e->d_nbr, Mold, Mnew, psi_old, psi_new, clamp,
+                                                    e->d_hub_row, e->d_hub_blk, e->d_P, 1, damp, e->d_partials));
+            } else {
+                DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, false>), dim3(e->n_hub), dim3(BLOCK), 0, hs,
+                                                    e->d_row_ptr, e->d_rev, e->d_nbr, Mold, Mnew, psi_old, psi_new, clamp,
+                                                    e->d_hub_row, e->d_hub_blk, e->d_P, int(e->dc), damp, e->d_partials));
+            }
+        }
+        HIPCHK(hipEventRecord(e->ev_join, hs));
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (e->timing) {
         if (e->ev_used + 2 > e->ev.size()) {
@@ -224,21 +254,7 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form) {
                                             int(e->dc), damp, e->d_partials));
     }
     if (e->timing) HIPCHK(hipEventRecord(e1, e->stream));
-    if (e->n_hub && psi_form) {
-        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi_hub<QQ>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
-                                            e->d_nbr, Mnew, psi_old, psi_new, e->d_hub_row, e->d_hub_blk, e->d_P,
-                                            int(e->dc), e->d_partials));
-    } else if (e->n_hub) {
-        if (e->dc == 2) {
-            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream,
-                                                e->d_row_ptr, e->d_rev, e->d_nbr, Mold, Mnew, psi_old, psi_new, clamp,
-                                                e->d_hub_row, e->d_hub_blk, e->d_P, 1, damp, e->d_partials));
-        } else {
-            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, false>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream,
-                                                e->d_row_ptr, e->d_rev, e->d_nbr, Mold, Mnew, psi_old, psi_new, clamp,
-                                                e->d_hub_row, e->d_hub_blk, e->d_P, int(e->dc), damp, e->d_partials));
-        }
-    }
+    if (e->n_hub) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
     uint32_t rows = e->n_blk;
     const double *part = fold_stage(e, &rows, int(e->Q), 1, e->Q + 1);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, e->stream, part, rows, int(e->Q), 0, e->d_P,
@@ -853,6 +869,9 @@ void sbmbp_destroy(sbmbp_engine_t *e) {
                     e->d_stage};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto ev : e->ev) hipEventDestroy(ev);
+    if (e->ev_fork) hipEventDestroy(e->ev_fork);
+    if (e->ev_join) hipEventDestroy(e->ev_join);
+    if (e->hub_stream) hipStreamDestroy(e->hub_stream);
     if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
     delete e;
 }

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Regenerates the evidence under profiles/ for one round on the GPU box:
+#   tools/profile_round.sh r01        (run from the repo root; writes gpurun_out/profile_<round>/ then summarises)
+# rocprofv3 is always given the program itself after `--`; PMC counters are collected in their own passes.
+set -u
+R=${1:-r01}
+OUT=gpurun_out/profile_$R
+mkdir -p $OUT
+export TMPDIR=/tmp
+for WL in C3 C2 C4 C5; do
+  echo "== bench $WL" >&2
+  python3 bench.py --workload $WL --no-cpu-baseline --converge > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err || exit 1
+  tail -c 600 $OUT/bench_$WL.json >&2
+  echo "== rocprofv3 stats $WL" >&2
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$WL -o run -- python3 bench.py --workload $WL --no-cpu-baseline > $OUT/stats_$WL.log 2>&1 || exit 1
+done
+echo "== bench C3 --gather messages" >&2
+python3 bench.py --workload C3 --no-cpu-baseline --gather messages > $OUT/bench_C3_messages.json 2> $OUT/bench_C3_messages.err || exit 1
+for CTR in FETCH_SIZE WRITE_SIZE TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum; do
+  echo "== pmc $CTR" >&2
+  rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d $OUT/pmc_$CTR -o run -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > $OUT/pmc_$CTR.log 2>&1 || echo "pmc $CTR failed" >&2
+done
+find $OUT -name "*kernel_trace.csv" -delete
+python3 tools/summarise_profiles.py $R

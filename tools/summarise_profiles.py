@@ -1,0 +1,38 @@
+"""Collects what tools/profile_round.sh produced under gpurun_out/profile_<round>/ into profiles/ (committed)."""
+import csv, glob, json, os, shutil, sys
+R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out", "profile_" + R)
+PROF = os.path.join(ROOT, "profiles")
+os.makedirs(PROF, exist_ok=True)
+for wl in ("C3", "C2", "C4", "C5"):
+    st = glob.glob(os.path.join(OUT, "stats_" + wl, "**", "*kernel_stats.csv"), recursive=True)
+    if st:
+        shutil.copy(st[0], os.path.join(PROF, "%s_%s_kernel_stats.csv" % (R, wl.lower())))
+    b = os.path.join(OUT, "bench_%s.json" % wl)
+    if os.path.exists(b):
+        line = [l for l in open(b) if l.startswith("{")]
+        if line:
+            open(os.path.join(PROF, "%s_%s_bench.json" % (R, wl.lower())), "w").write(line[-1])
+b = os.path.join(OUT, "bench_C3_messages.json")
+if os.path.exists(b):
+    line = [l for l in open(b) if l.startswith("{")]
+    if line:
+        open(os.path.join(PROF, "%s_c3_bench_message_gather.json" % R), "w").write(line[-1])
+counters = {}
+for d in sorted(glob.glob(os.path.join(OUT, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "k_sweep_psi" not in row.get("Kernel_Name", ""):
+                continue
+            counters.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+if counters:
+    bench = json.loads(open(os.path.join(PROF, "%s_c3_bench.json" % R)).read())
+    out = {"kernel": bench["roofline"]["kernel"], "workload": "C3 N=1e7 Q=4 c=10 (E2=%d)" % bench["config"]["E2"],
+           "command": "rocprofv3 --kernel-trace --pmc <counter> --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline (one pass per counter; tools/profile_round.sh)",
+           "counters": {k: {"per_launch_mean": sum(v) / len(v), "launches": len(v)} for k, v in counters.items()}}
+    json.dump(out, open(os.path.join(PROF, "%s_c3_pmc_k_sweep_psi.json" % R), "w"), indent=1)
+    print(json.dumps(out["counters"]))
+print("profiles/:", sorted(os.listdir(PROF)))
