@@ -40,7 +40,7 @@ extern "C" {
 #define SBMBP_ERR_UNSUPPORTED (-6) /* e.g. Q above SBMBP_MAX_Q */
 #define SBMBP_ERR_NOMEM (-7)
 
-#define SBMBP_MAX_Q 8 /* label count handled by the templated kernels */
+#define SBMBP_MAX_Q 16 /* label count handled by the templated kernels */
 
 typedef struct sbmbp_graph sbmbp_graph_t;   /* host-side CSR graph */
 typedef struct sbmbp_engine sbmbp_engine_t; /* device engine (one GPU) */

@@ -137,7 +137,7 @@ const double *fold_stage(sbmbp_engine *e, uint32_t *rows, int ncols_sum, int has
     return e->d_stage;
 }
 
-inline int frame_cap(uint32_t Q) { return FTPB * (Q <= 2 ? SBMBP_EPT_LO : (Q <= 4 ? SBMBP_EPT_MID : SBMBP_EPT_HI)); }
+inline int frame_cap(uint32_t Q) { return FTPB * (Q <= 2 ? SBMBP_EPT_LO : (Q <= 4 ? SBMBP_EPT_MID : (Q <= 8 ? SBMBP_EPT_HI : 1))); }
 inline int frame_rcap(uint32_t Q) { const int cap = frame_cap(Q); return cap / 2 > 64 ? cap / 2 : 64; }
 
 // Q/dc dispatch over the templated kernels
@@ -150,6 +150,14 @@ inline int frame_rcap(uint32_t Q) { const int cap = frame_cap(Q); return cap / 2
         case 6: { constexpr int QQ = 6; __VA_ARGS__; } break;           \
         case 7: { constexpr int QQ = 7; __VA_ARGS__; } break;           \
         case 8: { constexpr int QQ = 8; __VA_ARGS__; } break;           \
+        case 9: { constexpr int QQ = 9; __VA_ARGS__; } break;           \
+        case 10: { constexpr int QQ = 10; __VA_ARGS__; } break;         \
+        case 11: { constexpr int QQ = 11; __VA_ARGS__; } break;         \
+        case 12: { constexpr int QQ = 12; __VA_ARGS__; } break;         \
+        case 13: { constexpr int QQ = 13; __VA_ARGS__; } break;         \
+        case 14: { constexpr int QQ = 14; __VA_ARGS__; } break;         \
+        case 15: { constexpr int QQ = 15; __VA_ARGS__; } break;         \
+        case 16: { constexpr int QQ = 16; __VA_ARGS__; } break;         \
         default: set_error("unsupported Q"); return SBMBP_ERR_UNSUPPORTED; \
     }
 
@@ -466,14 +474,28 @@ double contract(const double *Mk, uint32_t Q, unsigned k, const std::vector<cons
     return acc;
 }
 
+// highest series order whose moment tensors (Q + Q^2 + ... + Q^K doubles) fit the reduction buffers: 4 up to Q = 9, 3 above
+int max_series_order(uint32_t Q) {
+    int K = 0;
+    uint64_t T = 0, sz = 1;
+    while (K < 4) {
+        sz *= Q;
+        if (T + sz > 8000) break;
+        T += sz;
+        ++K;
+    }
+    return K;
+}
+
 int choose_series_order(const sbmbp_engine *e, double wmax) {
-    if (e->series_order > 0) return std::min(e->series_order, 4);
+    const int Kmax = max_series_order(e->Q);
+    if (e->series_order > 0) return std::min(e->series_order, Kmax);
     // smallest K with N (wmax/N)^(K+1) / (2(K+1)) < 1e-12  (SURVEY A.4 truncation bound)
-    for (int K = 1; K <= 4; ++K) {
+    for (int K = 1; K <= Kmax; ++K) {
         double err = double(e->N) * std::pow(wmax / double(e->N), K + 1) / (2.0 * (K + 1));
         if (err < 1e-12) return K;
     }
-    return 4;
+    return Kmax;
 }
 
 // non-edge terms: out[0] = f_nonedge, out[1] = e_nonedge (if want_entropy)   (bp.cpp:675-741)
@@ -658,11 +680,12 @@ int overlap_impl(sbmbp_engine *e, double *ov, double *Cout) {
         std::vector<uint32_t> perm(Q);
         std::iota(perm.begin(), perm.end(), 0u);
         double best = -1.0;
-        do {  // compute_overlap (bp.cpp:775-811): all Q! permutations for Q <= 8
+        do {  // compute_overlap (bp.cpp:775-811): all Q! permutations for Q <= 8, the identity alone above (:784-790)
             double s = 0.0;
             for (uint32_t a = 0; a < Q; ++a) s += C[a * Q + perm[a]];
             s /= double(e->N);
             if (s > best) best = s;
+            if (Q > 8) break;
         } while (std::next_permutation(perm.begin(), perm.end()));
         *ov = best;
     }
@@ -760,7 +783,7 @@ int sbmbp_param_from_direct(uint32_t N, uint32_t Q, const double *pa, const doub
 
 int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint32_t dc, int device) {
     if (!out || !g) return SBMBP_ERR_ARG;
-    if (Q < 2 || Q > SBMBP_MAX_Q) { set_error("Q must be in [2, 8]"); return SBMBP_ERR_UNSUPPORTED; }
+    if (Q < 2 || Q > SBMBP_MAX_Q) { set_error("Q must be in [2, 16]"); return SBMBP_ERR_UNSUPPORTED; }
     if (dc > 2) { set_error("deg_corr_flag must be 0, 1 or 2"); return SBMBP_ERR_ARG; }
     if (g->n == 0) { set_error("empty graph"); return SBMBP_ERR_ARG; }
     int ndev = 0;
@@ -1176,7 +1199,7 @@ int sbmbp_set_timing(sbmbp_engine_t *e, int on) {
 
 int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *d, uint32_t Q, uint32_t dc, int device) {
     if (!out || !d || !d->row_ptr || (!d->nbr_local && d->n_edges) || !d->psi_buf0 || !d->psi_buf1 || !d->red_buf) return SBMBP_ERR_ARG;
-    if (Q < 2 || Q > SBMBP_MAX_Q) { set_error("Q must be in [2, 8]"); return SBMBP_ERR_UNSUPPORTED; }
+    if (Q < 2 || Q > SBMBP_MAX_Q) { set_error("Q must be in [2, 16]"); return SBMBP_ERR_UNSUPPORTED; }
     if (dc > 1) { set_error("sharded engines support deg_corr_flag 0 and 1"); return SBMBP_ERR_UNSUPPORTED; }
     if (d->n_own == 0 || d->n_global == 0) { set_error("empty shard"); return SBMBP_ERR_ARG; }
     if (d->row_ptr[0] != 0 || d->row_ptr[d->n_own] != d->n_edges || d->n_edges >= (uint64_t(1) << 32)) { set_error("shard row_ptr does not span [0, n_edges]"); return SBMBP_ERR_ARG; }
@@ -1470,10 +1493,11 @@ static void shard_nonedge_mats(const sbmbp_engine_t *e, std::vector<double> &mat
 }
 
 static int shard_series_order(const sbmbp_engine_t *e, double wmax) {
-    if (e->series_order > 0) return std::min(e->series_order, 4);
-    for (int K = 1; K <= 4; ++K)
+    const int Kmax = max_series_order(e->Q);
+    if (e->series_order > 0) return std::min(e->series_order, Kmax);
+    for (int K = 1; K <= Kmax; ++K)
         if (double(e->Nglob) * std::pow(wmax / double(e->Nglob), K + 1) / (2.0 * (K + 1)) < 1e-12) return K;
-    return 4;
+    return Kmax;
 }
 
 extern "C" {

@@ -19,7 +19,7 @@
 namespace sbmbp {
 
 constexpr int BLOCK = 256;
-constexpr int QMAX = 8;
+constexpr int QMAX = 16;
 
 // Parameter/state block in HBM, read through scalar loads by every workgroup and rewritten by
 // k_finalize after each sweep (arrays packed with stride Q).
@@ -62,7 +62,7 @@ constexpr int FTPB = SBMBP_FRAME_TPB;
 constexpr int FWAVES = FTPB / 64;
 
 template <int Q> struct frame_cfg {
-    static constexpr int EPT = (Q <= 2) ? SBMBP_EPT_LO : (Q <= 4 ? SBMBP_EPT_MID : SBMBP_EPT_HI);  // directed edges per lane
+    static constexpr int EPT = (Q <= 2) ? SBMBP_EPT_LO : (Q <= 4 ? SBMBP_EPT_MID : (Q <= 8 ? SBMBP_EPT_HI : 1));  // directed edges per lane
     static constexpr int CAP = FTPB * EPT;                 // edges per workgroup segment
     static constexpr int RCAP = (CAP / 2 > 64) ? CAP / 2 : 64;  // rows per workgroup segment
 };
@@ -1493,8 +1493,11 @@ k_row_sums(const uint32_t *__restrict__ row_ptr, const double *__restrict__ psi,
     __shared__ uint32_t sdeg[BLOCK];
     __shared__ uint32_t scl[BLOCK];
     constexpr int T = 2 * Q + Q * Q;
+    constexpr int PER = (T + BLOCK - 1) / BLOCK;  // output entries per thread: 1 up to Q = 15, 2 at Q = 16
     const int tid = threadIdx.x;
-    double acc = 0.0;  // thread t < T owns output entry t
+    double acc[PER];  // thread t owns output entries t, t + BLOCK, ...
+#pragma unroll
+    for (int j = 0; j < PER; ++j) acc[j] = 0.0;
     const uint32_t lo = blockIdx.x * rows_per_blk, hi = min(n_rows, lo + rows_per_blk);
     for (uint32_t base = lo; base < hi; base += BLOCK) {
         const uint32_t cnt = min(uint32_t(BLOCK), hi - base);
@@ -1505,16 +1508,22 @@ k_row_sums(const uint32_t *__restrict__ row_ptr, const double *__restrict__ psi,
             scl[tid] = true_conf ? true_conf[base + tid] : 0u;
         }
         __syncthreads();
-        if (tid < Q) {
-            for (uint32_t r = 0; r < cnt; ++r) acc += sp[r * Q + tid];
-        } else if (tid < 2 * Q) {
-            for (uint32_t r = 0; r < cnt; ++r) acc += double(sdeg[r]) * sp[r * Q + (tid - Q)];
-        } else if (tid < T) {
-            const uint32_t a = uint32_t(tid - 2 * Q) / Q, b = uint32_t(tid - 2 * Q) % Q;
-            for (uint32_t r = 0; r < cnt; ++r) acc += (scl[r] == a) ? sp[r * Q + b] : 0.0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int t = tid + j * BLOCK;
+            if (t < Q) {
+                for (uint32_t r = 0; r < cnt; ++r) acc[j] += sp[r * Q + t];
+            } else if (t < 2 * Q) {
+                for (uint32_t r = 0; r < cnt; ++r) acc[j] += double(sdeg[r]) * sp[r * Q + (t - Q)];
+            } else if (t < T) {
+                const uint32_t a = uint32_t(t - 2 * Q) / Q, b = uint32_t(t - 2 * Q) % Q;
+                for (uint32_t r = 0; r < cnt; ++r) acc[j] += (scl[r] == a) ? sp[r * Q + b] : 0.0;
+            }
         }
     }
-    if (tid < T) partials[size_t(blockIdx.x) * T + tid] = acc;
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+        if (tid + j * BLOCK < T) partials[size_t(blockIdx.x) * T + tid + j * BLOCK] = acc[j];
 }
 
 // row index of every directed edge (built once; used by reductions that need d_i per edge)

@@ -62,12 +62,30 @@ def best_perm_diff(psi, ref):
     """max |psi - ref| minimised over label permutations (label symmetry)"""
     import itertools
     Q = psi.shape[1]
+    if Q > 6:  # Q! is out of reach: match columns by total absolute difference (assignment problem), then measure
+        from scipy.optimize import linear_sum_assignment
+        cost = np.array([[np.abs(psi[:, a] - ref[:, b]).sum() for a in range(Q)] for b in range(Q)])
+        rows, cols = linear_sum_assignment(cost)  # ref column b <- psi column cols[b]
+        p = tuple(int(c) for c in cols)
+        return np.abs(psi[:, list(p)] - ref).max(), p
     best = None
     for p in itertools.permutations(range(Q)):
         d = np.abs(psi[:, list(p)] - ref).max()
         if best is None or d < best[0]:
             best = (d, p)
     return best
+
+
+def best_vector_perm(v, ref):
+    """permutation p minimising max |v[p] - ref| (exhaustive for small Q, assignment on |v_a - ref_b| above)"""
+    import itertools
+    Q = len(ref)
+    if Q > 6:
+        from scipy.optimize import linear_sum_assignment
+        cost = np.abs(np.asarray(v)[None, :] - np.asarray(ref)[:, None])
+        _, cols = linear_sum_assignment(cost)
+        return [int(c) for c in cols]
+    return list(min(itertools.permutations(range(Q)), key=lambda p: np.abs(np.asarray(v)[list(p)] - ref).max()))
 
 
 @pytest.fixture(scope="session")

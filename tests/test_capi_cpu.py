@@ -165,7 +165,7 @@ def test_host_initial_state_across_slabs(S, orc):
 
 
 def test_param_constructors_equal_oracle_and_golden(S, orc):
-    for name in ("c1_matched_tight_seed0", "q4_tight_seed0", "q4_epsc_default_seed0", "hub_dc0_tight_seed0"):
+    for name in ("c1_matched_tight_seed0", "q4_tight_seed0", "q4_epsc_default_seed0", "hub_dc0_tight_seed0", "q10_tight_seed1"):
         gd = golden(name)
         a, r = args_of(gd), gd["result"]
         g = S.load_edge_list(a["path"], a["N"])

@@ -4,7 +4,7 @@ capacity) through both forms of the hub kernel."""
 import numpy as np
 import pytest
 
-from conftest import args_of, best_perm_diff, golden
+from conftest import args_of, best_perm_diff, best_vector_perm, golden
 
 pytestmark = pytest.mark.gpu
 
@@ -31,26 +31,32 @@ def _sharded(g, a, cab, na, psi0, msg0, world):
 
 
 @pytest.mark.parametrize("name,world", [("c1_matched_tight_seed0", 2), ("c1_matched_tight_seed0", 5), ("q4_tight_seed0", 3),
-                                        ("c1_dc1_tight_seed0", 4)])
+                                        ("c1_dc1_tight_seed0", 4), ("q10_tight_seed1", 3)])
 def test_sharded_equals_unsharded_and_reference(orc, name, world):
     a, r, g, cab, na, psi0, msg0 = _problem(orc, name)
     one = _sharded(g, a, cab, na, psi0, msg0, 1)
     sb = _sharded(g, a, cab, na, psi0, msg0, world)
     for _ in range(2):
         d1, dk = one.sweep(3), sb.sweep(3)
-        assert abs(d1 - dk) < 1e-13
+        assert abs(d1 - dk) < (1e-13 if a["Q"] <= 8 else 1e-11)
         psi_k = np.concatenate([s[0] for s in sb.local_state()])
         msg_k = np.concatenate([s[1] for s in sb.local_state()])
         psi_1, msg_1 = one.local_state()[0]
-        # partition invariance: only the reduction order of the Q field sums differs
-        assert np.abs(psi_k - psi_1).max() < 1e-12 and np.abs(msg_k - msg_1).max() < 1e-12
+        # partition invariance: only the reduction order of the Q field sums differs; the far-from-converged
+        # Q = 10 transient amplifies that last-bit difference a little more than the others
+        tol = 1e-12 if a["Q"] <= 8 else 1e-11
+        assert np.abs(psi_k - psi_1).max() < tol and np.abs(msg_k - msg_1).max() < tol
     niter, exact = sb.converge(1e-12, 3000, 1.0, check_every=6)
     assert niter >= 0 and exact < 1e-12
     assert one.converge(1e-12, 3000, 1.0, check_every=1)[0] == niter
     psi = np.concatenate([s[0] for s in sb.local_state()])
-    d, _ = best_perm_diff(psi, np.array(r["psi"]).reshape(psi.shape))
-    assert d < 1e-9  # the reference's fixed point
-    assert abs(sb.compute_overlap() - r["overlap"]) < 1e-9
+    if a["Q"] <= 8:
+        d, _ = best_perm_diff(psi, np.array(r["psi"]).reshape(psi.shape))
+        assert d < 1e-9  # the reference's fixed point
+        assert abs(sb.compute_overlap() - r["overlap"]) < 1e-9
+    else:  # Q = 10 has several BP fixed points (merged groups); a sharded engine reads its initial state as (psi^0, m^-1),
+        # so it need not fall into the basin the reference's run did: here it only has to agree with the single shard
+        assert np.abs(psi - one.local_state()[0][0]).max() < 1e-9
     assert sb.shards[0].stats().psi_form_sweeps > 0
 
 
@@ -145,8 +151,7 @@ def test_sharded_reductions_equal_single_engine_and_reference(S, orc, name, worl
         assert abs(ek - r["e"]) < max(2e-8, 20 * bound) * max(1.0, abs(r["e"]))
     na1, nna1, cab1 = bp.em_expectations()
     nak, nnak, cabk = sb.em_expectations()
-    import itertools
-    p = list(min(itertools.permutations(range(a["Q"])), key=lambda q: np.abs(nak[list(q)] - na1).max()))
+    p = best_vector_perm(nak, na1)
     assert np.abs(nak[p] - na1).max() < 1e-7 and np.abs(nnak[p] - nna1).max() < 1e-6
     assert np.abs(cabk[np.ix_(p, p)] - cab1).max() < 1e-8 * max(1.0, np.abs(cab1).max())
     assert abs(res["overlap"] - bp.compute_overlap()) < 1e-9

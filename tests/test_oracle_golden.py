@@ -53,7 +53,7 @@ def test_csr_dedup_and_selfloop(orc):
     "c1_matched_default_seed0", "c1_matched_tight_seed0", "c1_matched_tight_seed5",
     "c1_matched_damped_seed0", "c1_matched_beta08_seed0", "c1_dc1_tight_seed0", "c1_dc2_tight_seed0",
     "c1_dc1_default_seed0", "c1_dc2_default_seed0", "c1_planted_i1_seed0", "q4_tight_seed0",
-    "q4_epsc_default_seed0", "hub_dc1_tight_seed0", "hub_dc0_tight_seed0",
+    "q4_epsc_default_seed0", "hub_dc1_tight_seed0", "hub_dc0_tight_seed0", "q10_tight_seed1",
 ])
 def test_async_infer_bit_exact(orc, name):
     gd = golden(name)
@@ -91,6 +91,7 @@ def test_messages_layout_bit_exact(orc):
 @pytest.mark.parametrize("name,large", [
     ("c1_node_update_seed0", False), ("c1_node_update_large_seed0", True),
     ("c1_node_update_dc1_seed0", False), ("c1_node_update_dc2_seed0", False), ("q4_node_update_seed1", False),
+    ("q10_node_update_seed1", False),
 ])
 def test_single_node_update_known_answer(orc, name, large):
     gd = golden(name)
@@ -116,7 +117,8 @@ def test_three_async_sweeps(orc):
     assert (psi.ravel() == np.array(r["psi"])).all()
 
 
-@pytest.mark.parametrize("name", ["c1_em_expect_seed0", "c1_em_expect_dc1_seed0", "c1_em_expect_dc2_seed0", "q4_em_expect_seed0"])
+@pytest.mark.parametrize("name", ["c1_em_expect_seed0", "c1_em_expect_dc1_seed0", "c1_em_expect_dc2_seed0", "q4_em_expect_seed0",
+                                  "q10_em_expect_seed1"])
 def test_em_expectations_bit_exact(orc, name):
     gd = golden(name)
     a, r = args_of(gd), gd["result"]
@@ -144,7 +146,7 @@ def test_learning_bit_exact(orc, name):
 @pytest.mark.parametrize("name,tol,mix", [
     ("c1_matched_tight_seed0", 1e-10, 1.0), ("c1_matched_beta08_seed0", 1e-10, 1.0), ("c1_dc1_tight_seed0", 1e-10, 1.0),
     ("c1_dc2_tight_seed0", 1e-10, 1.0), ("q4_tight_seed0", 1e-10, 1.0), ("c1_planted_i1_seed0", 1e-10, 1.0),
-    ("hub_dc0_tight_seed0", 1e-9, 0.1), ("hub_dc1_tight_seed0", 1e-9, 1.0),
+    ("hub_dc0_tight_seed0", 1e-9, 0.1), ("hub_dc1_tight_seed0", 1e-9, 1.0), ("q10_tight_seed1", 1e-10, 1.0),
 ])
 def test_sync_fixed_point_equals_reference(orc, name, tol, mix):
     gd = golden(name)
@@ -158,7 +160,10 @@ def test_sync_fixed_point_equals_reference(orc, name, tol, mix):
     assert d < tol
     f, parts = bp.free_energy(0)
     assert abs(f - r["f"]) <= 1e-9 * max(1.0, abs(r["f"]))
-    assert abs(bp.overlap() - r["overlap"]) < 1e-9
+    if a["Q"] <= 8:
+        assert abs(bp.overlap() - r["overlap"]) < 1e-9
+    else:  # the reference scores the identity labelling only above Q = 8 (bp.cpp:784-790): relabel, then compare
+        assert abs(psi[:, list(perm)][np.arange(a["N"]), a["true_conf"]].sum() / a["N"] - r["overlap"]) < 1e-9
 
 
 @pytest.mark.parametrize("name", ["c1_matched_tight_seed0", "q4_tight_seed0"])
