@@ -122,6 +122,33 @@ def test_hub_rows_both_forms_and_oracle(S, orc, Q, dc):
         assert np.abs(parts - oparts).max() < 1e-9 * max(1.0, np.abs(oparts).max())
 
 
+@pytest.mark.parametrize("Q,dc,world", [(3, 1, 3), (2, 0, 2)])
+def test_sharded_with_hub_rows(S, orc, Q, dc, world):
+    """hub rows (one workgroup each) inside the chunks of a shard: sweeps, convergence and free energy equal the single shard"""
+    from sbm_bp_amd.distributed import LocalComm, ShardedBP
+    N = 6000
+    pairs = _hub_graph(N, 1700, 3)
+    g = S.Graph.from_edges(pairs, N)
+    row_ptr, nbr, _ = g.csr()
+    tc = (np.arange(N) * Q // N).astype(np.uint32)
+    cab = np.full((Q, Q), 0.004 if dc else 1.0) + np.eye(Q) * (0.02 if dc else 5.0)
+    na = np.array([N // Q] * Q, dtype=np.uint32)
+    runs = []
+    for w in (1, world):
+        sb = ShardedBP.from_csr(row_ptr, nbr, Q, dc, LocalComm(w), n_chunks=4)
+        sb.init_messages_device(5, tc)
+        sb.expand_bp_params(cab, na, 1.0)
+        assert sum(sh.stats().n_hub_rows for sh in sb.shards) >= 2
+        d = [sb.sweep(1) for _ in range(4)]
+        psi = np.concatenate([s[0] for s in sb.local_state()])
+        msg = np.concatenate([s[1] for s in sb.local_state()])
+        runs.append((d, psi, msg, sb.compute_free_energy(), sb.compute_overlap()))
+    (d1, p1, m1, f1, o1), (dk, pk, mk, fk, ok) = runs
+    assert np.abs(np.array(d1) - np.array(dk)).max() < 1e-12
+    assert np.abs(p1 - pk).max() < 1e-12 and np.abs(m1 - mk).max() < 1e-12
+    assert abs(f1 - fk) < 1e-10 * max(1.0, abs(f1)) and abs(o1 - ok) < 1e-12
+
+
 @pytest.mark.parametrize("name,world", [("c1_matched_tight_seed0", 3), ("q4_tight_seed0", 2), ("c1_dc1_tight_seed0", 4)])
 def test_sharded_reductions_equal_single_engine_and_reference(S, orc, name, world):
     """free energy, entropy, EM expectations over shards (all-reduced partials) vs the single engine with the
