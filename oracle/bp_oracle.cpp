@@ -399,6 +399,8 @@ double sweep_sync(bp_t &s, double damp) {
             continue;
         }
         b.assign(size_t(d) * Q, 0.0);
+        const bool long_row = d > 32;
+        std::vector<int> Ae(Q, 0);
         for (uint32_t q = 0; q < Q; ++q) A[q] = 1.0;
         for (uint32_t l = 0; l < d; ++l) {
             double dl = double(g.deg(g.nbr[k0 + l]));
@@ -414,6 +416,10 @@ double sweep_sync(bp_t &s, double damp) {
                 b[size_t(l) * Q + q] = acc;
                 bmax = std::max(bmax, acc);
             }
+            if (long_row) {  // one binary exponent per component (see below)
+                for (uint32_t q = 0; q < Q; ++q) { int k; A[q] = std::frexp(A[q] * b[size_t(l) * Q + q], &k); Ae[q] += k; }
+                continue;
+            }
             double amax = 0.0;
             for (uint32_t q = 0; q < Q; ++q) { A[q] *= b[size_t(l) * Q + q]; amax = std::max(amax, A[q]); }
             if (amax > 0.0 && (amax < 1e-100 || amax > 1e100)) for (uint32_t q = 0; q < Q; ++q) A[q] /= amax;
@@ -422,6 +428,19 @@ double sweep_sync(bp_t &s, double damp) {
         // dc != 0: exp(-d_i h/N) underflows in every component for hub rows; shifting by min_q h changes only a
         // common factor (the reference's large-degree path works in the log domain with a max-shift, :850-868)
         double hmin = *std::min_element(s.h.begin(), s.h.end());
+        if (long_row) {
+            // Rows above 32 edges: partial products can be extreme in opposite directions, so a common rescaling would
+            // flush the smaller component of each to zero. Components keep their own exponent and the row is finished
+            // in the log domain with a max-shift, as the reference's large-degree path does (:844-868).
+            double m = -1e300;
+            std::vector<double> lp(Q);
+            for (uint32_t q = 0; q < Q; ++q) {
+                double g = (s.dc == 0) ? s.beta : di;
+                lp[q] = std::log(A[q]) + double(Ae[q]) * 0.6931471805599453 + std::log(s.eta[q]) - g * s.h[q] / s.N;
+                m = std::max(m, lp[q]);
+            }
+            for (uint32_t q = 0; q < Q; ++q) { A[q] = std::exp(lp[q] - m); tot += A[q]; }
+        } else
         for (uint32_t q = 0; q < Q; ++q) {
             double F = (s.dc == 0) ? s.exph[q] : std::exp(-di * (s.h[q] - hmin) / s.N);
             A[q] = A[q] * s.eta[q] * F;

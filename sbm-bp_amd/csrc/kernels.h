@@ -270,19 +270,94 @@ __device__ __forceinline__ double apply_field(const dev_params *__restrict__ P, 
     return tot;
 }
 
-// log( sum_q A[q] eta[q] F_i[q] ) with A carrying a removed power-of-two exponent ex (f_site, bp.cpp:446-502)
-template <int Q>
-__device__ __forceinline__ double log_partition(const dev_params *__restrict__ P, int dc, double di, const double (&A)[Q], int ex) {
-    double lp[Q], m = -1.0e300;
+// ---- long rows: products with ONE EXPONENT PER COMPONENT ------------------------------------------------
+// A row of several hundred edges can have partial products that are extreme in opposite directions (one half of
+// the neighbours favouring group a by 1e+300, the other half group b): with a common exponent the smaller
+// component of each partial product is flushed to zero and the row ends as 0 x 0. So above BIG_ROW edges (wave
+// products) and for hub rows (workgroup products) every component carries its own binary exponent, and the row is
+// finished in the log domain, as the reference's large-degree path does (bp.cpp:844-868).
+template <int Q> __device__ __forceinline__ void x_norm(double (&A)[Q], int (&ae)[Q]) {
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        lp[q] = log(A[q]) + P->logeta[q] - (dc ? di : P->beta) * P->hN[q];
-        m = fmax(m, lp[q]);
+        int k;
+        A[q] = frexp(A[q], &k);  // 0 stays 0 (k = 0); NaN/Inf stay what they are
+        ae[q] += k;
     }
-    double s = 0.0;
+}
+// psi~[q] = A[q] 2^ae[q] eta[q] F_i[q], returned relative to its largest component (in A); the return value is the
+// sum of the returned components and *lmax the log of the factor taken out (log_partition = *lmax + log(sum))
+template <int Q>
+__device__ __forceinline__ double apply_field_x(const dev_params *__restrict__ P, int dc, double di, double (&A)[Q], const int (&ae)[Q],
+                                                double *lmax = nullptr) {
+    if (lmax == nullptr) {  // sweeps: when the exponents span less than 2^900 nothing can be flushed, so skip the logs
+        int emax = ae[0], emin = ae[0];
 #pragma unroll
-    for (int q = 0; q < Q; ++q) s += exp(lp[q] - m);
-    return m + log(s) + double(ex) * 0.6931471805599453;
+        for (int q = 1; q < Q; ++q) { emax = max(emax, ae[q]); emin = min(emin, ae[q]); }
+        if (emax - emin < 900) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) A[q] = ldexp(A[q], ae[q] - emax);
+            return apply_field<Q>(P, dc, di, A);
+        }
+    }
+    double lp[Q], m = -1.0e300;
+    const double g = dc ? di : P->beta;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        lp[q] = log(A[q]) + double(ae[q]) * 0.6931471805599453 + P->logeta[q] - g * P->hN[q];
+        m = fmax(m, lp[q]);  // fmax ignores a NaN operand only if the other is a number: an all-NaN row stays NaN below
+    }
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { A[q] = exp(lp[q] - m); tot += A[q]; }
+    if (lmax) *lmax = m;
+    return tot;
+}
+// log( sum_q A[q] 2^ae[q] eta[q] F_i[q] )   (f_site, bp.cpp:446-502)
+template <int Q>
+__device__ __forceinline__ double log_partition_x(const dev_params *__restrict__ P, int dc, double di, const double (&A)[Q], const int (&ae)[Q]) {
+    double t[Q], lmax;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) t[q] = A[q];
+    const double tot = apply_field_x<Q>(P, dc, di, t, ae, &lmax);
+    return lmax + log(tot);
+}
+// e_site of one row (bp.cpp:506-560): sum_q w_q (-h_q/N) / sum_q w_q with w_q = C[q] 2^ce[q] eta_q exp(-h_q/N)
+template <int Q>
+__device__ __forceinline__ double entropy_site_x(const dev_params *__restrict__ P, const double (&C)[Q], const int (&ce)[Q]) {
+    double lw[Q], m = -1.0e300;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        lw[q] = log(C[q]) + double(ce[q]) * 0.6931471805599453 + P->logeta[q] - P->hN[q];
+        m = fmax(m, lw[q]);
+    }
+    double num = 0.0, den = 0.0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const double w = exp(lw[q] - m);
+        den += w;
+        num += w * (-P->hN[q]);
+    }
+    return num / den;
+}
+// product of the workgroup's per-thread partial products; every thread returns with the result
+template <int Q> __device__ __forceinline__ void block_product_x(double (&A)[Q], int (&ae)[Q], double *sAq, int *sEq) {
+    const int tid = threadIdx.x;
+    x_norm<Q>(A, ae);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { sAq[tid * Q + q] = A[q]; sEq[tid * Q + q] = ae[q]; }
+    __syncthreads();
+    for (int s = BLOCK / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { A[q] *= sAq[(tid + s) * Q + q]; ae[q] += sEq[(tid + s) * Q + q]; }
+            x_norm<Q>(A, ae);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { sAq[tid * Q + q] = A[q]; sEq[tid * Q + q] = ae[q]; }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { A[q] = sAq[q]; ae[q] = sEq[q]; }
 }
 
 // Product over a row's edges out of LDS by a whole wave: lanes take strided edges, then a shuffle
@@ -290,22 +365,23 @@ __device__ __forceinline__ double log_partition(const dev_params *__restrict__ P
 // bitwise, so the result is deterministic). Used for rows above BIG_ROW edges, where the lane-per-row
 // loop would serialise hundreds of LDS reads while the rest of the workgroup waits.
 constexpr int BIG_ROW = 32;
-template <int Q> __device__ __forceinline__ void row_product_wave(const double *sb, int es, int ee, double (&A)[Q]) {
+template <int Q> __device__ __forceinline__ void row_product_wave(const double *sb, int es, int ee, double (&A)[Q], int (&ae)[Q]) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int q = 0; q < Q; ++q) A[q] = 1.0;
+    for (int q = 0; q < Q; ++q) { A[q] = 1.0; ae[q] = 0; }
     for (int e = es + lane; e < ee; e += 64) {
         double b[Q];
         load_vec<Q>(&sb[e * Q], b);
 #pragma unroll
         for (int q = 0; q < Q; ++q) A[q] *= b[q];
-        rescale_pow2<Q>(A);
+        if ((((e - es) >> 6) & 3) == 3) x_norm<Q>(A, ae);  // four factors of O(W) stay far inside the double range
     }
+    x_norm<Q>(A, ae);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
-        for (int q = 0; q < Q; ++q) A[q] *= __shfl_xor(A[q], o, 64);
-        rescale_pow2<Q>(A);  // partners hold identical values, so they rescale identically
+        for (int q = 0; q < Q; ++q) { A[q] *= __shfl_xor(A[q], o, 64); ae[q] += __shfl_xor(ae[q], o, 64); }
+        x_norm<Q>(A, ae);  // partners hold identical values, so they renormalise identically
     }
 }
 
@@ -405,9 +481,17 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
     double Sacc[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) Sacc[q] = 0.0;
-    auto finish_row = [&](int r, double di, double (&A)[Q]) {
+    auto finish_row = [&](int r, double di, double (&A)[Q], const int *ae /* per-component exponents of a long row, or null */) {
         double pv[Q];
-        const double tot = apply_field<Q>(P, dc, di, A);
+        double tot;
+        if (ae) {
+            int x[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) x[q] = ae[q];
+            tot = apply_field_x<Q>(P, dc, di, A, x);
+        } else {
+            tot = apply_field<Q>(P, dc, di, A);
+        }
         store_vec<Q>(&sA[r * Q], A);
         const double inv = 1.0 / tot;
         const double gi = dc ? di : 1.0;
@@ -436,7 +520,7 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
                 for (int q = 0; q < Q; ++q) A[q] *= b[q];
                 rescale_pow2<Q>(A);
             }
-            finish_row(r, di, A);
+            finish_row(r, di, A, nullptr);
         }
     }
     if (sbig)  // uniform: written before the barrier that ends phase 1
@@ -444,8 +528,9 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
         const int es = int(srp[r]), ee = int(srp[r + 1]);
         if (ee - es > BIG_ROW && !sfl[r]) {
             double A[Q];
-            row_product_wave<Q>(sb, es, ee, A);
-            if ((tid & 63) == 0) finish_row(r, double(ee - es), A);
+            int ae[Q];
+            row_product_wave<Q>(sb, es, ee, A, ae);
+            if ((tid & 63) == 0) finish_row(r, double(ee - es), A, ae);
         }
     }
     __syncthreads();
@@ -476,15 +561,16 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
                 if (!ok) {  // exact cavity product when a division is unusable (b == 0 or overflow)
                     const int es = int(srp[r]), ee = int(srp[r + 1]);
                     const double di = double(ee - es);
+                    int ce[Q];
 #pragma unroll
-                    for (int q = 0; q < Q; ++q) cav[q] = 1.0;
+                    for (int q = 0; q < Q; ++q) { cav[q] = 1.0; ce[q] = 0; }
                     for (int e = es; e < ee; ++e) {
                         if (e == le) continue;
 #pragma unroll
                         for (int q = 0; q < Q; ++q) cav[q] *= sb[e * Q + q];
-                        rescale_pow2<Q>(cav);
+                        x_norm<Q>(cav, ce);
                     }
-                    tot = apply_field<Q>(P, dc, di, cav);
+                    tot = apply_field_x<Q>(P, dc, di, cav, ce);
                 }
                 const double inv = 1.0 / tot;
 #pragma unroll
@@ -596,9 +682,17 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
 #pragma unroll
     for (int q = 0; q < Q; ++q) Sacc[q] = 0.0;
     double md = 0.0;
-    auto finish_row = [&](int r, double di, double (&A)[Q]) {
+    auto finish_row = [&](int r, double di, double (&A)[Q], const int *ae /* per-component exponents of a long row, or null */) {
         double pv[Q];
-        const double tot = apply_field<Q>(P, dc, di, A);
+        double tot;
+        if (ae) {
+            int x[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) x[q] = ae[q];
+            tot = apply_field_x<Q>(P, dc, di, A, x);
+        } else {
+            tot = apply_field<Q>(P, dc, di, A);
+        }
         store_vec<Q>(&sA[r * Q], A);
         const double inv = 1.0 / tot;
         const double gi = dc ? di : 1.0;
@@ -619,7 +713,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
                 for (int q = 0; q < Q; ++q) A[q] *= b[q];
                 rescale_pow2<Q>(A);
             }
-            finish_row(r, double(ee - es), A);
+            finish_row(r, double(ee - es), A, nullptr);
         }
     }
     if (sbig)  // uniform: written before the barrier that ends phase 1
@@ -627,8 +721,9 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
         const int es = int(srp[r]), ee = int(srp[r + 1]);
         if (ee - es > BIG_ROW) {
             double A[Q];
-            row_product_wave<Q>(sb, es, ee, A);
-            if ((tid & 63) == 0) finish_row(r, double(ee - es), A);
+            int ae[Q];
+            row_product_wave<Q>(sb, es, ee, A, ae);
+            if ((tid & 63) == 0) finish_row(r, double(ee - es), A, ae);
         }
     }
     __syncthreads();
@@ -666,7 +761,7 @@ k_sweep_psi_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict
                 double *__restrict__ partials) {
     if (P->stop) return;
     __shared__ double sAq[BLOCK * Q];
-    __shared__ int sex[BLOCK];
+    __shared__ int sEq[BLOCK * Q];
     __shared__ double sred[4 * (Q + 1)];
     const int tid = threadIdx.x;
     const uint32_t i = hub_row[blockIdx.x];
@@ -677,9 +772,9 @@ k_sweep_psi_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict
     for (int q = 0; q < Q; ++q) Sacc[q] = 0.0;
     double md = 0.0;
     double A[Q];
-    int ex = 0;
+    int ae[Q];
 #pragma unroll
-    for (int q = 0; q < Q; ++q) A[q] = 1.0;
+    for (int q = 0; q < Q; ++q) { A[q] = 1.0; ae[q] = 0; }
     auto incoming_field = [&](uint32_t le, double (&mo)[Q], double (&b)[Q]) {
         double pl[Q], bo[Q], inc[Q];
         load_vec<Q>(psi_old + size_t(nbr[e0 + le]) * Q, pl);
@@ -698,26 +793,10 @@ k_sweep_psi_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict
         incoming_field(le, mo, b);
 #pragma unroll
         for (int q = 0; q < Q; ++q) A[q] *= b[q];
-        ex += rescale_pow2<Q>(A);
+        x_norm<Q>(A, ae);
     }
-    store_vec<Q>(&sAq[tid * Q], A);
-    sex[tid] = ex;
-    __syncthreads();
-    for (int s = BLOCK / 2; s > 0; s >>= 1) {
-        if (tid < s) {
-            double o[Q];
-            load_vec<Q>(&sAq[(tid + s) * Q], o);
-#pragma unroll
-            for (int q = 0; q < Q; ++q) A[q] *= o[q];
-            ex += sex[tid + s];
-            ex += rescale_pow2<Q>(A);
-            store_vec<Q>(&sAq[tid * Q], A);
-            sex[tid] = ex;
-        }
-        __syncthreads();
-    }
-    load_vec<Q>(&sAq[0], A);
-    const double tot = apply_field<Q>(P, dc, di, A);
+    block_product_x<Q>(A, ae, sAq, sEq);
+    const double tot = apply_field_x<Q>(P, dc, di, A, ae);
     const double inv = 1.0 / tot;
     if (tid == 0) {
         double pv[Q];
@@ -805,7 +884,7 @@ k_sweep_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ r
             double *__restrict__ partials) {
     if (P->stop) return;
     __shared__ double sAq[BLOCK * Q];
-    __shared__ int sex[BLOCK];
+    __shared__ int sEq[BLOCK * Q];
     __shared__ double sred[4 * (Q + 1)];
     const int tid = threadIdx.x;
     const uint32_t i = hub_row[blockIdx.x];
@@ -831,9 +910,9 @@ k_sweep_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ r
         }
     } else {
         double A[Q];
-        int ex = 0;
+        int ae[Q];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) A[q] = 1.0;
+        for (int q = 0; q < Q; ++q) { A[q] = 1.0; ae[q] = 0; }
         for (uint32_t le = tid; le < d; le += BLOCK) {
             double m[Q], b[Q];
             load_msg<Q>(Mold, rev[e0 + le], m);
@@ -842,26 +921,10 @@ k_sweep_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ r
             edge_field<Q, DC2>(P, m, didl, b);
 #pragma unroll
             for (int q = 0; q < Q; ++q) A[q] *= b[q];
-            ex += rescale_pow2<Q>(A);
+            x_norm<Q>(A, ae);
         }
-        store_vec<Q>(&sAq[tid * Q], A);
-        sex[tid] = ex;
-        __syncthreads();
-        for (int s = BLOCK / 2; s > 0; s >>= 1) {
-            if (tid < s) {
-                double o[Q];
-                load_vec<Q>(&sAq[(tid + s) * Q], o);
-#pragma unroll
-                for (int q = 0; q < Q; ++q) A[q] *= o[q];
-                ex += sex[tid + s];
-                ex += rescale_pow2<Q>(A);
-                store_vec<Q>(&sAq[tid * Q], A);
-                sex[tid] = ex;
-            }
-            __syncthreads();
-        }
-        load_vec<Q>(&sAq[0], A);  // every lane: the row product (common exponent dropped: only ratios matter)
-        const double tot = apply_field<Q>(P, dc, di, A);
+        block_product_x<Q>(A, ae, sAq, sEq);  // every lane: the row product, one exponent per component
+        const double tot = apply_field_x<Q>(P, dc, di, A, ae);
         const double inv = 1.0 / tot;
         if (tid == 0) {
             double pv[Q];
@@ -1062,32 +1125,28 @@ k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
             const int es = int(srp[r]), ee = int(srp[r + 1]);
             const double di = double(ee - es);
             double A[Q];
-            int ex = 0;
+            int ae[Q];
 #pragma unroll
-            for (int q = 0; q < Q; ++q) A[q] = 1.0;
+            for (int q = 0; q < Q; ++q) { A[q] = 1.0; ae[q] = 0; }
             for (int e = es; e < ee; ++e) {
 #pragma unroll
                 for (int q = 0; q < Q; ++q) A[q] *= sb[e * Q + q];
-                ex += rescale_pow2<Q>(A);
+                if (((e - es) & 7) == 7) x_norm<Q>(A, ae);  // eight factors of O(W) stay far inside the double range
             }
-            acc[0] += log_partition<Q>(P, dc, di, A, ex);  // log Z_i  (bp.cpp:446-502)
+            x_norm<Q>(A, ae);
+            acc[0] += log_partition_x<Q>(P, dc, di, A, ae);  // log Z_i  (bp.cpp:446-502)
             if (want_entropy) {  // e_site (bp.cpp:506-560): no beta, weights exp(a + log eta - h/N)
                 double C[Q];
+                int ce[Q];
 #pragma unroll
-                for (int q = 0; q < Q; ++q) C[q] = 1.0;
+                for (int q = 0; q < Q; ++q) { C[q] = 1.0; ce[q] = 0; }
                 for (int e = es; e < ee; ++e) {
 #pragma unroll
                     for (int q = 0; q < Q; ++q) C[q] *= sc[e * Q + q];
-                    rescale_pow2<Q>(C);
+                    if (((e - es) & 7) == 7) x_norm<Q>(C, ce);
                 }
-                double num = 0.0, den = 0.0;
-#pragma unroll
-                for (int q = 0; q < Q; ++q) {
-                    const double w = C[q] * P->eta[q] * exp(-P->hN[q]);
-                    den += w;
-                    num += w * (-P->hN[q]);
-                }
-                acc[2] += num / den;
+                x_norm<Q>(C, ce);
+                acc[2] += entropy_site_x<Q>(P, C, ce);
             }
         }
     }
@@ -1102,7 +1161,7 @@ k_fe_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev,
          double *__restrict__ partials) {
     __shared__ double sAq[BLOCK * Q];
     __shared__ double sCq[BLOCK * Q];
-    __shared__ int sex[BLOCK];
+    __shared__ int sEq[BLOCK * Q];
     __shared__ double sred[4 * (FE_NP + 1)];
     const int tid = threadIdx.x;
     const uint32_t i = hub_row[blockIdx.x];
@@ -1110,9 +1169,9 @@ k_fe_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev,
     const double di = double(d);
     double acc[FE_NP] = {0.0, 0.0, 0.0, 0.0};
     double A[Q], C[Q];
-    int ex = 0;
+    int ae[Q], ce[Q];
 #pragma unroll
-    for (int q = 0; q < Q; ++q) { A[q] = 1.0; C[q] = 1.0; }
+    for (int q = 0; q < Q; ++q) { A[q] = 1.0; C[q] = 1.0; ae[q] = 0; ce[q] = 0; }
     for (uint32_t le = tid; le < d; le += BLOCK) {
         double mi[Q], mo[Q], b[Q];
         load_msg<Q>(Min ? Min : M, Min ? size_t(e0 + le) : size_t(rev[e0 + le]), mi);
@@ -1122,7 +1181,7 @@ k_fe_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev,
         edge_field<Q, DC2>(P, mi, didl, b);
 #pragma unroll
         for (int q = 0; q < Q; ++q) A[q] *= b[q];
-        ex += rescale_pow2<Q>(A);
+        x_norm<Q>(A, ae);
         if (want_entropy) {
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
@@ -1131,47 +1190,21 @@ k_fe_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev,
                 for (int t = 0; t < Q; ++t) a += P->cab[t * Q + q] * mi[t];
                 C[q] *= a;
             }
-            rescale_pow2<Q>(C);
+            x_norm<Q>(C, ce);
         }
         double ln, en;
         edge_terms<Q, DC2>(P, mi, mo, didl, ln, en);
         acc[1] += ln;
         if (want_entropy) acc[3] += en;
     }
-    store_vec<Q>(&sAq[tid * Q], A);
-    store_vec<Q>(&sCq[tid * Q], C);
-    sex[tid] = ex;
-    __syncthreads();
-    for (int s = BLOCK / 2; s > 0; s >>= 1) {
-        if (tid < s) {
-            double o[Q];
-            load_vec<Q>(&sAq[(tid + s) * Q], o);
-#pragma unroll
-            for (int q = 0; q < Q; ++q) A[q] *= o[q];
-            ex += sex[tid + s];
-            ex += rescale_pow2<Q>(A);
-            store_vec<Q>(&sAq[tid * Q], A);
-            sex[tid] = ex;
-            load_vec<Q>(&sCq[(tid + s) * Q], o);
-#pragma unroll
-            for (int q = 0; q < Q; ++q) C[q] *= o[q];
-            rescale_pow2<Q>(C);
-            store_vec<Q>(&sCq[tid * Q], C);
-        }
+    block_product_x<Q>(A, ae, sAq, sEq);
+    if (want_entropy) {  // uniform
         __syncthreads();
+        block_product_x<Q>(C, ce, sCq, sEq);
     }
     if (tid == 0) {
-        acc[0] += log_partition<Q>(P, dc, di, A, ex);
-        if (want_entropy) {
-            double num = 0.0, den = 0.0;
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const double w = C[q] * P->eta[q] * exp(-P->hN[q]);
-                den += w;
-                num += w * (-P->hN[q]);
-            }
-            acc[2] += num / den;
-        }
+        acc[0] += log_partition_x<Q>(P, dc, di, A, ae);
+        if (want_entropy) acc[2] += entropy_site_x<Q>(P, C, ce);
     }
     block_reduce_store<FE_NP>(acc, 0.0, sred, partials + size_t(hub_blk[blockIdx.x]) * (FE_NP + 1));
 }
