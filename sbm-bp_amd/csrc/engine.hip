@@ -854,6 +854,9 @@ int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint3
     if (e->E2) {
         TRYHIP(hipMemcpyAsync(e->d_rev, g->rev.data(), e->E2 * 4, hipMemcpyHostToDevice, e->stream));
         TRYHIP(hipMemcpyAsync(e->d_nbr, g->nbr.data(), e->E2 * 4, hipMemcpyHostToDevice, e->stream));
+    } else {  // the sweeps' branch-free loads read nbr[0] / rev[0] even when there are no edges
+        TRYHIP(hipMemsetAsync(e->d_rev, 0, 4, e->stream));
+        TRYHIP(hipMemsetAsync(e->d_nbr, 0, 4, e->stream));
     }
     std::vector<uint32_t> blk_e0(blk_row.size());  // edge offset of every segment start, next to the row range
     for (size_t b = 0; b < blk_row.size(); ++b) blk_e0[b] = rp32[blk_row[b]];
@@ -1288,6 +1291,7 @@ int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *d, uint32_t
     TRY(dev_alloc(e, &e->d_stage, size_t(FOLD_BLOCKS) * FOLD_STRIDE_MAX));
     TRYHIP(hipMemcpyAsync(e->d_row_ptr, rp32.data(), rp32.size() * 4, hipMemcpyHostToDevice, e->stream));
     if (e->E2) TRYHIP(hipMemcpyAsync(e->d_nbr, d->nbr_local, e->E2 * 4, hipMemcpyHostToDevice, e->stream));
+    else TRYHIP(hipMemsetAsync(e->d_nbr, 0, 4, e->stream));  // the sweep's branch-free loads read nbr[0] even without edges
     std::vector<uint32_t> blk_e0(blk_row.size());  // edge offset of every segment start, next to the row range
     for (size_t b = 0; b < blk_row.size(); ++b) blk_e0[b] = rp32[blk_row[b]];
     TRYHIP(hipMemcpyAsync(e->d_blk_row, blk_row.data(), blk_row.size() * 4, hipMemcpyHostToDevice, e->stream));

@@ -105,3 +105,40 @@ def test_random_instance_against_the_oracle(S, orc, seed):
     assert _close(na1, na2, 1e-9) and _close(nna1, nna2, 1e-9)
     assert _close(cab1, cab2, 1e-8), (cab1, cab2)
     assert abs(bp.compute_overlap() - ob.overlap()) < 1e-11
+
+
+@pytest.mark.parametrize("seed", range(200, 230))
+def test_random_instance_sharded_against_one_shard(S, seed):
+    """the sharded engine (2-5 HIP shards in this process, chunked exchange) against a single shard on random instances:
+    iterates to 1e-12, then free energy, entropy, EM expectations, overlap"""
+    from sbm_bp_amd.distributed import LocalComm, ShardedBP
+    t = _instance(seed)
+    rng = np.random.default_rng(seed)
+    Q, N, dc = t["Q"], max(t["N"], 12), min(t["dc"], 1)  # shards: marginal-gather form (dc 0/1, cab > 0, no clamps)
+    if N != t["N"]:
+        t["pairs"] = (t["pairs"] % N).astype(np.uint32)
+        t["tc"] = rng.integers(0, Q, size=N).astype(np.uint32)
+    cab = np.where(t["cab"] == 0, t["cab"][t["cab"] > 0].min(), t["cab"])
+    if dc != t["dc"]:
+        cab = cab * t["cab"].max() ** -1 * 0.01
+    world = int(rng.integers(2, 6))
+    g = S.Graph.from_edges(t["pairs"], N)
+    row_ptr, nbr, _ = g.csr()
+    runs = []
+    for w in (1, world):
+        sb = ShardedBP.from_csr(row_ptr, nbr, Q, dc, LocalComm(w), n_chunks=int(rng.integers(1, 5)) if w > 1 else 1)
+        sb.init_messages_device(seed, t["tc"])
+        sb.expand_bp_params(cab, t["na"], 1.0)
+        d = [sb.sweep(1) for _ in range(3)]
+        psi = np.concatenate([s[0] for s in sb.local_state()])
+        msg = np.concatenate([s[1] for s in sb.local_state()])
+        fe = sb.compute_free_energy()
+        en = sb.compute_entropy()
+        em = sb.em_expectations()
+        runs.append((d, psi, msg, fe, en, em, sb.compute_overlap()))
+    (d1, p1, m1, f1, e1, em1, o1), (dk, pk, mk, fk, ek, emk, ok) = runs
+    assert np.abs(np.array(d1) - np.array(dk)).max() < 1e-12
+    assert np.abs(p1 - pk).max() < 1e-12 and (m1.size == 0 or np.abs(m1 - mk).max() < 1e-12)
+    assert _close(fk, f1, 1e-10) and _close(ek, e1, 1e-9) and abs(o1 - ok) < 1e-12
+    for a, b in zip(emk, em1):
+        assert _close(a, b, 1e-9)
