@@ -105,6 +105,17 @@ def test_random_instance_against_the_oracle(S, orc, seed):
     assert _close(na1, na2, 1e-9) and _close(nna1, nna2, 1e-9)
     assert _close(cab1, cab2, 1e-8), (cab1, cab2)
     assert abs(bp.compute_overlap() - ob.overlap()) < 1e-11
+    # run on to convergence: the engine's batched driver (2-step hint, exact check, device-side stop flag) must stop
+    # where the oracle's plain loop does
+    it1, last1 = bp.converge(1e-9, 400, 1.0)
+    it2, last2 = ob.converge_sync(1e-9, 400, 1.0)
+    if it1 >= 0 and it2 >= 0:
+        # the engine checks the exact criterion only once its 2-step hint is within 8 x crit: where the differences do
+        # not fall monotonically it can pass the first crossing by a few sweeps (never stop early)
+        assert it2 - 1 <= it1 <= it2 + 4 and last1 < 1e-9, (it1, it2, last1)
+        assert np.abs(bp.get_state()[0] - ob.get_state()[0]).max() < 1e-7
+    else:
+        assert (it1 < 0) == (it2 < 0) or min(last1, last2) < 4e-9, (it1, it2, last1, last2)
 
 
 @pytest.mark.parametrize("seed", range(200, 230))
