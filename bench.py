@@ -204,6 +204,12 @@ def main():
                          "traffic": pmc_traffic(args.workload, kname, world, E2_total, N, Q),
                          "kernel": kname, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
         }
+        if sharded:  # what rank 0 ships per sweep: the numbers needed to read a multi-GPU result
+            p0, sh0 = runner.plans[0], runner.shards[0]
+            per_peer = p0.send_counts.astype(float) * sh0.ncomp * 8 / 1e6
+            out["config"]["exchange"] = {"chunks": int(p0.n_chunks), "payload_components": int(sh0.ncomp),
+                                         "halo_rows": int(p0.n_halo), "sent_MB_per_sweep": round(float(per_peer.sum()), 2),
+                                         "busiest_peer_MB_per_sweep": round(float(per_peer.max()) if len(per_peer) else 0.0, 2)}
         if rehearsal:
             out["rehearsal"] = "ranks share cuda:0, gloo collectives staged through the host: not a measurement"
         if sweeps_to_converge is not None:
