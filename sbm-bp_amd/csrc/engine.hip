@@ -1120,8 +1120,18 @@ int sbmbp_inference(sbmbp_engine_t *e, float conv_crit, uint32_t time_conv, floa
     NOT_SHARD(e);
     // belief_propagation::inference (bp.cpp:77-99); crit and damping arrive as float, compared as double (:406)
     CHK(run_sweeps(e, double(conv_crit), time_conv, double(dumping_rate), &out->niter, &out->last_maxdiff));
-    CHK(free_energy_impl(e, &out->free_energy, nullptr));
-    CHK(entropy_impl(e, &out->entropy, nullptr));
+    if (e->dc != 0) {  // entropy is NaN in the reference for deg_corr_flag != 0: only the free-energy pass runs
+        CHK(free_energy_impl(e, &out->free_energy, nullptr));
+        CHK(entropy_impl(e, &out->entropy, nullptr));
+    } else {  // one pass over the messages yields the site/edge/non-edge terms of both quantities
+        if (!e->field_fresh) CHK(refresh_field(e));
+        double se[4], ne[2];
+        CHK(site_edge_terms(e, true, se));
+        CHK(nonedge_terms(e, true, ne));
+        const double N = double(e->N);
+        out->free_energy = -(se[0] / N) + se[1] / (2.0 * N) + ne[0];
+        out->entropy = -(se[2] / N) + se[3] / (2.0 * N) - ne[1];
+    }
     CHK(overlap_impl(e, &out->overlap, nullptr));
     return SBMBP_OK;
 }
