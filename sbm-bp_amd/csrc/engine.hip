@@ -937,10 +937,58 @@ int sbmbp_init_messages(sbmbp_engine_t *e, uint32_t flag, const int32_t *conf, c
     if (!e) return SBMBP_ERR_ARG;
     if (flag >= 4) { set_error("bp_messages_init_flag must be < 4"); return SBMBP_ERR_ARG; }  // assert at bp.cpp:106
     if (flag != 0 && !conf) { set_error("init flag != 0 needs a conf vector"); return SBMBP_ERR_ARG; }
-    std::unique_ptr<double[]> psi(new double[size_t(e->N) * e->Q]), msg(new double[std::max<size_t>(1, e->E2 * e->Q)]);  // not zero-filled
-    init_state_host(e->N, e->h_row_ptr.data(), e->E2, e->Q, flag, conf, seed, psi.get(), msg.get());
     CHK(upload_labels(e, conf, true_conf, flag, conditional));
-    return sbmbp_set_state(e, psi.get(), msg.get());
+    // the state is generated in slabs of consecutive vertices and each slab is uploaded (marginal rows as they are,
+    // messages through the Q -> Q-1 record conversion) while the host already generates the next one
+    const uint32_t Q = e->Q;
+    double *tmp = nullptr;
+    uint64_t tmp_cap = 0;
+    hipError_t herr = hipSuccess;
+    double *pin_psi = nullptr, *pin_msg = nullptr;  // page-locked slab buffers: the uploads run at link speed
+    state_sink sink;
+    sink.alloc = [&](uint64_t np, uint64_t nm, double **pb, double **mb) {
+        if (hipHostMalloc(reinterpret_cast<void **>(&pin_psi), np * 8, hipHostMallocDefault) != hipSuccess) { pin_psi = nullptr; return false; }
+        if (hipHostMalloc(reinterpret_cast<void **>(&pin_msg), nm * 8, hipHostMallocDefault) != hipSuccess) {
+            (void)hipHostFree(pin_psi);
+            pin_psi = pin_msg = nullptr;
+            return false;
+        }
+        *pb = pin_psi;
+        *mb = pin_msg;
+        return true;
+    };
+    sink.put = [&](uint32_t lo, uint32_t hi, const double *prow, const double *mrow) {
+        if (herr != hipSuccess || hi <= lo) return;
+        herr = hipMemcpyAsync(e->d_psi[e->pcur] + size_t(lo) * Q, prow, size_t(hi - lo) * Q * 8, hipMemcpyHostToDevice, e->stream);
+        const uint64_t k0 = e->h_row_ptr[lo], nm = uint64_t(e->h_row_ptr[hi]) - k0;
+        if (herr == hipSuccess && nm) {
+            if (nm > tmp_cap) {
+                if (tmp) { (void)hipStreamSynchronize(e->stream); (void)hipFree(tmp); tmp = nullptr; }
+                herr = hipMalloc(&tmp, nm * Q * 8);
+                tmp_cap = herr == hipSuccess ? nm : 0;
+            }
+            if (herr == hipSuccess) herr = hipMemcpyAsync(tmp, mrow, nm * Q * 8, hipMemcpyHostToDevice, e->stream);
+            if (herr == hipSuccess) {
+                hipLaunchKernelGGL(k_msgs_to_records, dim3(uint32_t((nm * (Q - 1) + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, e->stream, tmp, nm,
+                                   int(Q), e->d_M[e->cur] + k0 * (Q - 1));
+                herr = hipGetLastError();
+            }
+        }
+        if (herr == hipSuccess) herr = hipStreamSynchronize(e->stream);  // the slab buffers are reused by the next slab
+    };
+    init_state_host(e->N, e->h_row_ptr.data(), e->E2, Q, flag, conf, seed, nullptr, nullptr, &sink);
+    if (tmp) (void)hipFree(tmp);
+    if (pin_psi) (void)hipHostFree(pin_psi);
+    if (pin_msg) (void)hipHostFree(pin_msg);
+    HIPCHK(herr);
+    // a sharded engine takes the declared state as (psi^0, m^-1): sweep 0 reads the buffer it then overwrites
+    if (e->E2 && e->sharded)
+        HIPCHK(hipMemcpyAsync(e->d_M[e->cur ^ 1], e->d_M[e->cur], e->E2 * (Q - 1) * 8, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->have_state = true;
+    e->field_fresh = false;
+    e->psi_consistent = false;
+    return SBMBP_OK;
 }
 
 int sbmbp_host_init_state(const sbmbp_graph_t *g, uint32_t Q, uint32_t flag, const int32_t *conf, uint32_t seed, double *psi,

@@ -2,6 +2,9 @@
 // each function replaces.
 #include "host_graph.h"
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -13,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <random>
 #include <thread>
 
@@ -118,15 +122,39 @@ int graph_from_pairs(sbmbp_graph &g, const uint32_t *pairs, uint64_t n_pairs, ui
     });
     std::vector<uint32_t>().swap(adj);
     pt.lap("compaction");
+    // Reverse index by counting: rows are sorted, so while the edge array is read front to back (sources ascending) the
+    // c-th time vertex j appears as a neighbour, the source is j's c-th smallest neighbour: rev[k] = row_ptr[j] + c.
+    // Each thread owns a range of target vertices (its counters stay in cache), scans the whole array and handles the
+    // entries that fall in its range; no searches, no random reads of other rows.
     g.rev.resize(g.nbr.size());
-    parallel_ranges(n, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
-        for (uint64_t i = lo; i < hi; ++i)
-            for (uint64_t k = g.row_ptr[i]; k < g.row_ptr[i + 1]; ++k) {
-                uint32_t j = g.nbr[k];
-                const uint32_t *b = g.nbr.data() + g.row_ptr[j], *e = g.nbr.data() + g.row_ptr[j + 1];
-                g.rev[k] = uint32_t(std::lower_bound(b, e, uint32_t(i)) - g.nbr.data());
+    {
+        const uint64_t e2 = g.nbr.size();
+        unsigned parts = std::max(1u, std::min<unsigned>(nt, unsigned(e2 / 262144 + 1)));
+        std::vector<uint32_t> seen(n, 0);
+        // target ranges with equal shares of the edges
+        std::vector<uint32_t> cut(parts + 1, n);
+        cut[0] = 0;
+        for (unsigned t = 1; t < parts; ++t)
+            cut[t] = uint32_t(std::lower_bound(g.row_ptr.begin(), g.row_ptr.end(), e2 * t / parts) - g.row_ptr.begin());
+        for (unsigned t = 1; t <= parts; ++t) cut[t] = std::max(cut[t], cut[t - 1]);
+        cut[parts] = n;
+        std::vector<std::thread> th;
+        auto work = [&](unsigned t) {
+            const uint32_t lo = cut[t], hi = cut[t + 1];
+            if (lo >= hi) return;
+            const uint32_t *nb = g.nbr.data();
+            uint32_t *rv = g.rev.data();
+            const uint64_t *rp = g.row_ptr.data();
+            uint32_t *sn = seen.data();
+            for (uint64_t k = 0; k < e2; ++k) {
+                const uint32_t j = nb[k];
+                if (j - lo < hi - lo) rv[k] = uint32_t(rp[j]) + sn[j]++;
             }
-    });
+        };
+        for (unsigned t = 1; t < parts; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
     pt.lap("reverse index");
     return SBMBP_OK;
 }
@@ -309,14 +337,73 @@ void param_from_direct(uint32_t N, uint32_t Q, const double *pa, const double *c
 // previous slab into normalised vectors (a vertex's position in the stream follows from a prefix sum of
 // 1 + degree over the vertices that draw at all).
 namespace {
+#if defined(__x86_64__)
+// AVX2 bodies of the two MT19937 loops (eight words per step; the scalar code below is the definition)
+// (no lambdas here: a lambda body does not inherit the function's target attribute)
+#define SBMBP_MT_STEP(I, FAR)                                                                                           \
+    do {                                                                                                                \
+        const __m256i hi_ = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + (I)));                             \
+        const __m256i lo_ = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + (I) + 1));                         \
+        const __m256i far_ = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + (FAR)));                          \
+        const __m256i y_ = _mm256_or_si256(_mm256_and_si256(hi_, upper), _mm256_and_si256(lo_, lower));                 \
+        const __m256i mag_ = _mm256_and_si256(_mm256_sub_epi32(zero, _mm256_and_si256(y_, one)), matrix);               \
+        _mm256_storeu_si256(reinterpret_cast<__m256i *>(s + (I)),                                                       \
+                            _mm256_xor_si256(_mm256_xor_si256(far_, _mm256_srli_epi32(y_, 1)), mag_));                  \
+    } while (0)
+#define SBMBP_MT_SCALAR(I, NXT, FAR)                                                  \
+    do {                                                                              \
+        const uint32_t y_ = (s[(I)] & 0x80000000u) | (s[(NXT)] & 0x7fffffffu);        \
+        s[(I)] = s[(FAR)] ^ (y_ >> 1) ^ ((0u - (y_ & 1u)) & 0x9908b0dfu);             \
+    } while (0)
+__attribute__((target("avx2"))) static void mt_twist_avx2(uint32_t *s) {
+    const __m256i upper = _mm256_set1_epi32(int(0x80000000u)), lower = _mm256_set1_epi32(0x7fffffff);
+    const __m256i one = _mm256_set1_epi32(1), matrix = _mm256_set1_epi32(int(0x9908b0dfu)), zero = _mm256_setzero_si256();
+    unsigned i = 0;
+    for (; i + 8 <= 227; i += 8) SBMBP_MT_STEP(i, i + 397);  // reads s[i+1 .. i+8] and s[i+397 .. i+404]: all still old
+    for (; i < 227; ++i) SBMBP_MT_SCALAR(i, i + 1, i + 397);
+    for (; i + 8 <= 623; i += 8) SBMBP_MT_STEP(i, i - 227);  // s[i-227 ..] are new values, s[i+1 .. i+8] old
+    for (; i < 623; ++i) SBMBP_MT_SCALAR(i, i + 1, i - 227);
+    SBMBP_MT_SCALAR(623, 0, 396);
+}
+#undef SBMBP_MT_STEP
+#undef SBMBP_MT_SCALAR
+__attribute__((target("avx2"))) static void mt_temper_avx2(const uint32_t *s, uint32_t *out, unsigned count) {
+    const __m256i b = _mm256_set1_epi32(int(0x9d2c5680u)), c = _mm256_set1_epi32(int(0xefc60000u));
+    unsigned i = 0;
+    for (; i + 8 <= count; i += 8) {
+        __m256i y = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + i));
+        y = _mm256_xor_si256(y, _mm256_srli_epi32(y, 11));
+        y = _mm256_xor_si256(y, _mm256_and_si256(_mm256_slli_epi32(y, 7), b));
+        y = _mm256_xor_si256(y, _mm256_and_si256(_mm256_slli_epi32(y, 15), c));
+        y = _mm256_xor_si256(y, _mm256_srli_epi32(y, 18));
+        _mm256_storeu_si256(reinterpret_cast<__m256i *>(out + i), y);
+    }
+    for (; i < count; ++i) {
+        uint32_t y = s[i];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        out[i] = y ^ (y >> 18);
+    }
+}
+static const bool g_have_avx2 = __builtin_cpu_supports("avx2");
+#else
+static const bool g_have_avx2 = false;
+#endif
+
 struct mt19937_words {  // MT19937 (Matsumoto & Nishimura 1998), same parameters and seeding as std::mt19937
-    uint32_t s[624];
+    uint32_t s[624 + 8];  // + 8: the vector loop's last load may touch (not use) words past the state
     unsigned pos = 624;
     explicit mt19937_words(uint32_t seed) {
         s[0] = seed;
         for (uint32_t i = 1; i < 624; ++i) s[i] = 1812433253u * (s[i - 1] ^ (s[i - 1] >> 30)) + i;
+        for (uint32_t i = 624; i < 632; ++i) s[i] = 0;
     }
     void twist() {
+        pos = 0;
+#if defined(__x86_64__)
+        if (g_have_avx2) { mt_twist_avx2(s); return; }
+#endif
         auto mix = [](uint32_t hi, uint32_t lo, uint32_t far) {
             uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
             return far ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
@@ -324,7 +411,6 @@ struct mt19937_words {  // MT19937 (Matsumoto & Nishimura 1998), same parameters
         for (unsigned i = 0; i < 227; ++i) s[i] = mix(s[i], s[i + 1], s[i + 397]);
         for (unsigned i = 227; i < 623; ++i) s[i] = mix(s[i], s[i + 1], s[i - 227]);
         s[623] = mix(s[623], s[0], s[396]);
-        pos = 0;
     }
     static uint32_t temper(uint32_t y) {
         y ^= y >> 11;
@@ -336,6 +422,10 @@ struct mt19937_words {  // MT19937 (Matsumoto & Nishimura 1998), same parameters
         while (count) {
             if (pos == 624) twist();
             const unsigned take = unsigned(std::min<uint64_t>(count, 624 - pos));
+#if defined(__x86_64__)
+            if (g_have_avx2) mt_temper_avx2(s + pos, out, take);
+            else
+#endif
             for (unsigned i = 0; i < take; ++i) out[i] = temper(s[pos + i]);
             pos += take; out += take; count -= take;
         }
@@ -352,7 +442,7 @@ inline double canonical(const uint32_t *w) {
 }  // namespace
 
 void init_state_host(uint32_t n, const uint32_t *row_ptr, uint64_t e2, uint32_t Q, uint32_t flag, const int32_t *conf,
-                     uint32_t seed, double *psi, double *msg) {
+                     uint32_t seed, double *psi, double *msg, const state_sink *sink) {
     phase_timer pt;
     (void)e2;
     auto planted = [&](uint32_t i) -> int32_t { return (flag == 0 || !conf) ? -1 : conf[i]; };
@@ -380,8 +470,27 @@ void init_state_host(uint32_t n, const uint32_t *row_ptr, uint64_t e2, uint32_t 
     if (n_slabs > 1) raw[1].resize(biggest);
     mt19937_words gen(seed);
     const unsigned nt = host_threads();
+    // with a sink the rows of a slab go to a reusable buffer that is handed over as soon as the slab is done (the engine
+    // uploads it while the generator thread is busy with the next slab); without, they go to the caller's full arrays
+    std::unique_ptr<double[]> pbuf, mbuf;
+    double *pslab = nullptr, *mslab = nullptr;
+    if (sink) {
+        uint64_t max_rows = 1, max_edges = 1;
+        for (size_t sl = 0; sl < n_slabs; ++sl) {
+            max_rows = std::max<uint64_t>(max_rows, slab_start[sl + 1] - slab_start[sl]);
+            max_edges = std::max<uint64_t>(max_edges, uint64_t(row_ptr[slab_start[sl + 1]]) - row_ptr[slab_start[sl]]);
+        }
+        if (!sink->alloc || !sink->alloc(max_rows * Q, max_edges * Q, &pslab, &mslab)) {
+            pbuf.reset(new double[max_rows * Q]);
+            mbuf.reset(new double[max_edges * Q]);
+            pslab = pbuf.get();
+            mslab = mbuf.get();
+        }
+    }
     auto consume = [&](size_t sl, const uint32_t *words) {
         const uint32_t lo = slab_start[sl], hi = slab_start[sl + 1];
+        double *const pbase = sink ? pslab - size_t(lo) * Q : psi;                 // row i at pbase + i*Q
+        double *const mbase = sink ? mslab - size_t(row_ptr[lo]) * Q : msg;        // edge k at mbase + k*Q
         // word offset of every vertex of the slab: prefix sum, then the rows are independent
         std::vector<uint64_t> off(size_t(hi - lo) + 1, 0);
         for (uint32_t i = lo; i < hi; ++i)
@@ -411,8 +520,8 @@ void init_state_host(uint32_t n, const uint32_t *row_ptr, uint64_t e2, uint32_t 
                         for (uint32_t q = 0; q < Q; ++q) dst[q] = (int32_t(q) == p) ? 1.0 : 0.0;
                     }
                 };
-                fill(&psi[size_t(i) * Q]);
-                for (uint64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) fill(&msg[k * Q]);
+                fill(pbase + size_t(i) * Q);
+                for (uint64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) fill(mbase + k * Q);
             }
         });
     };
@@ -421,6 +530,7 @@ void init_state_host(uint32_t n, const uint32_t *row_ptr, uint64_t e2, uint32_t 
         std::thread producer;
         if (sl + 1 < n_slabs) producer = std::thread([&, sl] { gen.fill(raw[(sl + 1) & 1].data(), slab_size[sl + 1]); });
         consume(sl, raw[sl & 1].data());
+        if (sink) sink->put(slab_start[sl], slab_start[sl + 1], pslab, mslab);
         if (producer.joinable()) producer.join();
     }
     pt.lap("initial state (mt19937)");

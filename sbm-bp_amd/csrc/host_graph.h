@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <string>
+#include <functional>
 #include <vector>
 
 struct sbmbp_graph {
@@ -34,8 +35,16 @@ void param_from_direct(uint32_t N, uint32_t Q, const double *pa, const double *c
 // init_messages (belief_propagation.cpp:101-217) on the out-ordered layout; fills psi (N*Q) and
 // msg (E2*Q), both caller-allocated (need not be initialised), from std::mt19937(seed) in the reference's
 // draw order.
+// With a sink, psi/msg may be null: the rows are produced in slabs of consecutive vertices [lo, hi) and each slab is
+// handed over when complete (psi_rows: (hi-lo)*Q doubles, msg_rows: (row_ptr[hi]-row_ptr[lo])*Q doubles, valid during the
+// call) while the generator already works on the next one.
+struct state_sink {
+    // optional: provide the two slab buffers (e.g. page-locked memory); default new[]
+    std::function<bool(uint64_t psi_doubles, uint64_t msg_doubles, double **psi_buf, double **msg_buf)> alloc;
+    std::function<void(uint32_t lo, uint32_t hi, const double *psi_rows, const double *msg_rows)> put;
+};
 void init_state_host(uint32_t n, const uint32_t *row_ptr, uint64_t e2, uint32_t Q, uint32_t flag, const int32_t *conf,
-                     uint32_t seed, double *psi, double *msg);
+                     uint32_t seed, double *psi, double *msg, const state_sink *sink = nullptr);
 
 }  // namespace sbmbp
 #endif
