@@ -173,6 +173,7 @@ int upload_params(sbmbp_engine *e, double crit) {
         P.eta[q] = e->eta[q];
         P.logeta[q] = std::log(e->eta[q]);
     }
+    for (uint32_t a = 0; a < Q * Q; ++a) P.logcab[a] = std::log(e->cab[a]);
     P.beta = e->beta;
     P.invN = 1.0 / double(e->Nglob);
     P.field_mix = e->field_mix;

@@ -26,6 +26,7 @@ constexpr int QMAX = 16;
 struct dev_params {
     double W[QMAX * QMAX];     // sweep weights: cab^beta (dc 0), cab (dc 1), pab = cab/N (dc 2)
     double cab[QMAX * QMAX];
+    double logcab[QMAX * QMAX];  // log cab (host): the entropy edge term weights cab log cab, not to be recomputed per edge
     double eta[QMAX];
     double logeta[QMAX];
     double hN[QMAX];           // h[q] / N
@@ -1045,7 +1046,7 @@ constexpr int FE_NP = 4;
 // cab (dc 1; the d_i d_l prefactor is a graph constant added on the host), x/(1+x) (dc 2).
 template <int Q, bool DC2>
 __device__ __forceinline__ void edge_terms(const dev_params *__restrict__ P, const double (&mi)[Q], const double (&mo)[Q],
-                                           double didl, double &log_norm, double &ent) {
+                                           double didl, int want_entropy, double &log_norm, double &ent) {
     double nl = 0.0, num = 0.0, den = 0.0;
 #pragma unroll
     for (int q1 = 0; q1 < Q; ++q1) {
@@ -1056,12 +1057,14 @@ __device__ __forceinline__ void edge_terms(const dev_params *__restrict__ P, con
             double we = P->cab[q1 * Q + q2];  // entropy uses cab without beta (bp.cpp:628-666)
             if (DC2) { double x = didl * wf; wf = x / (1.0 + x); we = wf; }
             nl += wf * pr;
-            den += we * pr;
-            num += we * log(P->cab[q1 * Q + q2]) * pr;
+            if (want_entropy) {  // uniform
+                den += we * pr;
+                num += we * P->logcab[q1 * Q + q2] * pr;
+            }
         }
     }
     log_norm = log(nl);
-    ent = num / den;
+    ent = want_entropy ? num / den : 0.0;
 }
 
 template <int Q, bool DC2>
@@ -1115,7 +1118,7 @@ k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
                     store_vec<Q>(&sc[le * Q], c);
                 }
                 double ln, en;
-                edge_terms<Q, DC2>(P, mi, mo, didl, ln, en);
+                edge_terms<Q, DC2>(P, mi, mo, didl, want_entropy, ln, en);
                 acc[1] += ln;
                 if (want_entropy) acc[3] += en;
             }
@@ -1193,7 +1196,7 @@ k_fe_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev,
             x_norm<Q>(C, ce);
         }
         double ln, en;
-        edge_terms<Q, DC2>(P, mi, mo, didl, ln, en);
+        edge_terms<Q, DC2>(P, mi, mo, didl, want_entropy, ln, en);
         acc[1] += ln;
         if (want_entropy) acc[3] += en;
     }
@@ -1227,7 +1230,9 @@ k_nonedge_adj(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__
     const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
     const int nrows = int(r1 - r0);
     const uint32_t e0 = row_ptr[r0];
+    __shared__ double sclc[Q * Q];  // cab log cab, once per workgroup instead of Q*Q logs per edge
     for (int r = threadIdx.x; r <= nrows; r += FTPB) srp[r] = row_ptr[r0 + r] - e0;
+    if (want_entropy && threadIdx.x < Q * Q) sclc[threadIdx.x] = cab[threadIdx.x] * log(cab[threadIdx.x]);
     __syncthreads();
     const int ne = int(srp[nrows]);
     double acc[NE_NP] = {0.0, 0.0};
@@ -1248,7 +1253,7 @@ k_nonedge_adj(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__
                 if (want_entropy) {
                     const double c = cab[q1 * Q + q2];
                     yc += c * pp;
-                    u += c * log(c) * pp;
+                    u += sclc[q1 * Q + q2] * pp;
                 }
             }
         }
@@ -1417,7 +1422,9 @@ k_nonedge_exact_adj(const uint32_t *__restrict__ row_ptr, const uint32_t *__rest
     const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
     const int nrows = int(r1 - r0);
     const uint32_t e0 = row_ptr[r0];
+    __shared__ double sclc[Q * Q];  // (cab/N) log cab, once per workgroup
     for (int r = threadIdx.x; r <= nrows; r += FTPB) srp[r] = row_ptr[r0 + r] - e0;
+    if (want_entropy && threadIdx.x < Q * Q) sclc[threadIdx.x] = (cab[threadIdx.x] * invN) * log(cab[threadIdx.x]);
     __syncthreads();
     const int ne = int(srp[nrows]);
     double acc[NE_NP] = {0.0, 0.0};
@@ -1436,7 +1443,7 @@ k_nonedge_exact_adj(const uint32_t *__restrict__ row_ptr, const uint32_t *__rest
                 f += Pmat[q1 * Q + q2] * pp;
                 if (want_entropy) {
                     const double c = cab[q1 * Q + q2];
-                    num += (c * invN) * log(c) * pp;
+                    num += sclc[q1 * Q + q2] * pp;
                     den += (1.0 - c * invN) * pp;
                 }
             }
