@@ -19,7 +19,7 @@ import os
 
 import numpy as np
 
-from sbm_bp_amd.plan import ShardPlan, partition_rows
+from sbm_bp_amd.plan import ShardPlan, block_cyclic_layout, busiest_link_rows, partition_rows, permute_csr
 
 HINT_SCALE = 8.0  # same rule as run_sweeps in csrc/engine.hip
 
@@ -224,6 +224,14 @@ class TorchDistComm:
     def all_gather(self, outs, ins):
         self.dist.all_gather_into_tensor(outs[0], ins[0])
 
+    def host_max(self, values):
+        """element-wise max of a short list of host integers over all ranks (setup-time decisions)"""
+        import torch
+        dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [int(x) for x in t.cpu().tolist()]
+
 
 class HostStagedComm(TorchDistComm):
     """rehearsal / debugging only: the same calls over a backend without device collectives (gloo), every
@@ -257,6 +265,9 @@ class LocalComm:
 
     def __init__(self, world):
         self.rank, self.world = 0, world
+
+    def host_max(self, values):
+        return [int(v) for v in values]
 
     def local_ranks(self):
         return list(range(self.world))
@@ -307,15 +318,49 @@ class ShardedBP:
 
     # -- construction -------------------------------------------------------------------------
     @classmethod
-    def from_csr(cls, row_ptr, nbr, Q, dc, comm, backend_factory=None, n_chunks=None):
-        bounds = partition_rows(row_ptr, comm.world)
+    def from_csr(cls, row_ptr, nbr, Q, dc, comm, backend_factory=None, n_chunks=None, interleave=1):
+        """interleave = k > 1 deals k*world row blocks round robin to the shards (plan.block_cyclic_layout) instead of
+        giving each one range; "auto" picks the k in (1, 2, 4) with the lightest busiest link. The vertices are renamed
+        so that every shard still owns one contiguous range: `self.order[p]` is the caller's id of vertex p, and
+        true_conf / global_marginals() translate at the boundary."""
+        world = comm.world
+        if interleave == "auto":
+            interleave = cls._choose_interleave(row_ptr, nbr, comm) if world > 1 else 1
+        interleave = max(1, int(interleave))
+        order = None
+        if interleave > 1 and world > 1:
+            order, bounds, bb = block_cyclic_layout(row_ptr, world, interleave)
+            row_ptr, nbr, _ = permute_csr(row_ptr, nbr, order, bb)
+        else:
+            interleave = 1
+            bounds = partition_rows(row_ptr, world)
         if n_chunks is None:  # SBMBP_SHARD_CHUNKS: tuning knob for the compute/exchange overlap (default 4)
-            n_chunks = 1 if comm.world == 1 else max(1, int(os.environ.get("SBMBP_SHARD_CHUNKS", "4")))
+            n_chunks = 1 if world == 1 else max(1, int(os.environ.get("SBMBP_SHARD_CHUNKS", "4")))
         plans = [ShardPlan(row_ptr, nbr, bounds, r, n_chunks) for r in comm.local_ranks()]
         self = cls(plans, Q, dc, comm, backend_factory)
         self.E2_global = int(len(nbr))
         self.bounds = bounds
+        self.order = order          # None: the caller's numbering
+        self.interleave = interleave
         return self
+
+    @staticmethod
+    def _choose_interleave(row_ptr, nbr, comm):
+        """k in (1, 2, 4) minimising the rows on the busiest link of any rank"""
+        cands = [k for k in (1, 2, 4) if k * comm.world <= max(1, len(row_ptr) - 1)]
+        load = [max(busiest_link_rows(row_ptr, nbr, comm.world, k, r) for r in comm.local_ranks()) for k in cands]
+        load = comm.host_max(load)
+        best = min(range(len(cands)), key=lambda i: (load[i], cands[i]))
+        # a different layout costs a larger halo: keep plain ranges unless the busiest link gets 40 % lighter
+        return cands[best] if load[best] < 0.6 * load[0] else 1
+
+    def to_caller_order(self, rows_new):
+        """rows in the engine's numbering (concatenated over all shards) -> the caller's numbering"""
+        if self.order is None:
+            return rows_new
+        out = np.empty_like(rows_new)
+        out[self.order] = rows_new
+        return out
 
     @classmethod
     def synthetic(cls, N, Q, c, eps, graph_seed, dc=0, seed=1234, comm=None):
@@ -327,15 +372,21 @@ class ShardedBP:
         g = S.Graph.from_edges(pairs, N)
         del pairs
         row_ptr, nbr, _ = g.csr()
-        self = cls.from_csr(row_ptr, nbr, Q, dc, comm)
+        # plain ranges unless SBMBP_SHARD_INTERLEAVE says otherwise ("auto" or k): on the planted benchmark graphs dealing
+        # blocks lightens the busiest link by at most 27 % (k = 4 at 8 shards) and pays with 1.7x the halo
+        il = os.environ.get("SBMBP_SHARD_INTERLEAVE", "1")
+        self = cls.from_csr(row_ptr, nbr, Q, dc, comm, interleave=il if il == "auto" else int(il))
         tc = synth.true_conf(N, Q)
         self.init_messages_device(seed, tc)
         self.expand_bp_params(synth.cab_matrix(Q, cin, cout), np.array(synth.group_sizes(N, Q), dtype=np.uint32), 1.0)
         return self
 
     def init_messages_device(self, seed, true_conf_global):
+        tc = np.asarray(true_conf_global)
+        if getattr(self, "order", None) is not None:
+            tc = tc[self.order]
         for sh, p in zip(self.shards, self.plans):
-            sh.init_messages_device(seed, np.asarray(true_conf_global)[p.row0:p.row0 + p.n_own])
+            sh.init_messages_device(seed, tc[p.row0:p.row0 + p.n_own])
 
     def expand_bp_params(self, cab, na, beta=1.0):
         self.cab = np.array(cab, dtype=np.float64)

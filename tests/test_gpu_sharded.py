@@ -244,3 +244,26 @@ def test_three_processes_share_one_gpu(orc, tmp_path, name, world):
     # the reference's fixed point; shards evaluate the non-edge term by the order-4 moment series (bound of SURVEY A.4)
     bound = a["N"] * (max(r["cab"]) / a["N"]) ** 5 / 10.0
     assert abs(float(res["fe"]) - r["f"]) < max(2e-9, 2 * bound) * max(1.0, abs(r["f"]))
+
+
+@pytest.mark.parametrize("name,world,k", [("q4_tight_seed0", 2, 2), ("c1_matched_tight_seed0", 3, 4)])
+def test_block_cyclic_layout_reaches_the_reference_fixed_point(orc, name, world, k):
+    """shards made of k row blocks each (plan.block_cyclic_layout): vertices renamed inside, same answers outside"""
+    from sbm_bp_amd.distributed import LocalComm, ShardedBP
+    from sbm_bp_amd.plan import edge_order
+    a, r, g, cab, na, psi0, msg0 = _problem(orc, name)
+    sb = ShardedBP.from_csr(g.row_ptr, g.nbr, a["Q"], a["dc"], LocalComm(world), interleave=k)
+    assert sb.interleave == k
+    sb.init_messages_device(7, a["true_conf"])
+    eo = edge_order(g.row_ptr, sb.order)
+    for sh, p in zip(sb.shards, sb.plans):
+        sh.set_state(psi0[sb.order][p.row0:p.row0 + p.n_own], msg0[eo][p.edge0:p.edge0 + p.n_edges])
+    sb.expand_bp_params(cab, na, a["beta"])
+    niter, exact = sb.converge(1e-12, 3000, 1.0)
+    assert niter >= 0
+    psi = sb.to_caller_order(np.concatenate([s[0] for s in sb.local_state()]))
+    d, _ = best_perm_diff(psi, np.array(r["psi"]).reshape(psi.shape))
+    assert d < 1e-9
+    assert abs(sb.compute_overlap() - r["overlap"]) < 1e-9
+    bound = a["N"] * (max(r["cab"]) / a["N"]) ** 5 / 10.0
+    assert abs(sb.compute_free_energy() - r["f"]) < max(2e-9, 2 * bound) * max(1.0, abs(r["f"]))

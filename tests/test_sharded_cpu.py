@@ -108,3 +108,36 @@ def test_two_processes_over_gloo(orc, tmp_path):
     assert int(res["niter"]) == niter
     assert np.abs(res["psi"] - ref.local_state()[0][0]).max() < 1e-12
     assert abs(float(res["overlap"]) - ref.compute_overlap()) < 1e-12
+
+
+@pytest.mark.parametrize("world,k", [(2, 2), (3, 2), (4, 4)])
+def test_block_cyclic_layout_is_the_same_problem(orc, world, k):
+    """dealing k*world row blocks round robin (plan.block_cyclic_layout) renames the vertices and nothing else: same
+    graph, every shard one contiguous range, and the sharded run lands on the same marginals in the caller's order"""
+    from sbm_bp_amd.distributed import LocalComm, ShardedBP
+    from sbm_bp_amd.plan import block_cyclic_layout, busiest_link_rows, edge_order, permute_csr
+    from shard_numpy_backend import NumpyShardBackend
+    a, r, g, cab, na, psi0, msg0 = _problem(orc)
+    order, bounds, bb = block_cyclic_layout(g.row_ptr, world, k)
+    assert sorted(order.tolist()) == list(range(g.N)) and bounds[0] == 0 and bounds[-1] == g.N
+    rp2, nb2, inv = permute_csr(g.row_ptr, g.nbr, order, bb)
+    eo = edge_order(g.row_ptr, order)
+    assert (np.diff(rp2.astype(np.int64)) == np.diff(g.row_ptr.astype(np.int64))[order]).all()
+    assert (order[nb2] == g.nbr[eo]).all()  # edge for edge the same neighbours under the renaming
+    assert busiest_link_rows(g.row_ptr, g.nbr, world, 1, 0) > 0
+    plain = _sharded(g, a, cab, na, psi0, msg0, world)
+    plain.converge(1e-12, 3000, 1.0)
+    sb = ShardedBP.from_csr(g.row_ptr, g.nbr, a["Q"], a["dc"], LocalComm(world), interleave=k,
+                            backend_factory=lambda p: NumpyShardBackend(p, a["Q"], a["dc"]))
+    assert sb.interleave == k and (sb.order == order).all()
+    for sh in sb.shards:
+        sh.init_from_global(psi0[order], msg0[eo], np.asarray(a["true_conf"])[order])
+    sb.expand_bp_params(cab, na, a["beta"])
+    niter, _ = sb.converge(1e-12, 3000, 1.0)
+    assert niter >= 0
+    psi = sb.to_caller_order(np.concatenate([s[0] for s in sb.local_state()]))
+    assert np.abs(psi - np.concatenate([s[0] for s in plain.local_state()])).max() < 1e-10
+    assert abs(sb.compute_overlap() - plain.compute_overlap()) < 1e-10
+    # the link-load estimate used by interleave="auto" equals what the plan really sends
+    for rk, p in enumerate(sb.plans):
+        assert busiest_link_rows(g.row_ptr, g.nbr, world, k, rk) == int(p.send_counts.max())
