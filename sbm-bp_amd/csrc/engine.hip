@@ -78,6 +78,7 @@ struct sbmbp_engine {
     double beta = 1.0;
     double sum_log_didl = 0.0;  // sum over directed edges of log(d_i d_l) (dc 1 constant of f_site/f_edge)
     bool have_params = false, have_state = false, has_clamp = false, field_fresh = false;
+    bool clamp_onehot = false;  // the clamped rows hold the one-hot state of init flag 1/3: the marginal-gather sweep stays exact
     bool w_positive = false;     // every cab entry > 0: the marginal-gather sweep is well defined
     bool psi_consistent = false; // psi == marginals of the message pair held in d_M (set by an undamped sweep)
     int gather_mode = 0;         // 0 = automatic, 1 = always gather messages (explicit form)
@@ -225,7 +226,7 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form) {
         if (e->n_hub && psi_form) {
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi_hub<QQ>), dim3(e->n_hub), dim3(BLOCK), 0, hs, e->d_row_ptr,
                                                 e->d_nbr, Mnew, psi_old, psi_new, e->d_hub_row, e->d_hub_blk, e->d_P,
-                                                int(e->dc), e->d_partials));
+                                                int(e->dc), e->d_partials, clamp));
         } else if (e->n_hub) {
             if (e->dc == 2) {
                 DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, hs,
@@ -251,8 +252,14 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form) {
         HIPCHK(hipEventRecord(e0, e->stream));
     }
     if (psi_form) {
-        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
-                                            Mnew, psi_old, psi_new, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), e->d_partials));
+        if (clamp) {
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, true>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
+                                                Mnew, psi_old, psi_new, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), e->d_partials, clamp));
+        } else {
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
+                                                Mnew, psi_old, psi_new, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), e->d_partials,
+                                                (const int32_t *)nullptr));
+        }
     } else if (e->dc == 2) {
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, true>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
                                             e->d_rev, e->d_nbr, Mold, Mnew, psi_old, psi_new, clamp, e->d_blk_row, e->d_blk_e0, e->d_P,
@@ -313,7 +320,7 @@ int message_diff(sbmbp_engine *e, double *out) {
 }
 
 bool psi_form_allowed(const sbmbp_engine *e, double damping) {
-    return e->gather_mode == 0 && damping == 1.0 && !e->has_clamp && e->dc != 2 && e->w_positive && e->E2 > 0;
+    return e->gather_mode == 0 && damping == 1.0 && (!e->has_clamp || e->clamp_onehot) && e->dc != 2 && e->w_positive && e->E2 > 0;
 }
 
 // The in-kernel hint of k_sweep_psi is the 2-step message difference.
@@ -389,7 +396,7 @@ int run_sweeps(sbmbp_engine *e, double crit, uint32_t max_sweeps, double damping
     }
     e->sweeps += executed;
     e->psi_sweeps += n_psi;
-    if (executed > 0) e->psi_consistent = (damping == 1.0 && !e->has_clamp && e->w_positive);
+    if (executed > 0) e->psi_consistent = (damping == 1.0 && (!e->has_clamp || e->clamp_onehot) && e->w_positive);
     e->field_fresh = (e->field_mix >= 1.0) && executed > 0;
     if (niter) *niter = result_iter;
     if (last) *last = exact;
@@ -989,6 +996,7 @@ int sbmbp_init_messages(sbmbp_engine_t *e, uint32_t flag, const int32_t *conf, c
     e->have_state = true;
     e->field_fresh = false;
     e->psi_consistent = false;
+    e->clamp_onehot = (flag == 1 || flag == 3);  // clamped rows now hold one-hot marginals and messages
     return SBMBP_OK;
 }
 
@@ -1084,6 +1092,7 @@ int sbmbp_set_state(sbmbp_engine_t *e, const double *psi, const double *msg_out)
     if (psi && (msg_out || e->E2 == 0)) e->have_state = true;  // a graph without edges has no messages
     e->field_fresh = false;
     e->psi_consistent = false;
+    e->clamp_onehot = false;  // an arbitrary state: clamped rows need the general (message-gather) sweep
     return SBMBP_OK;
 }
 int sbmbp_get_state(sbmbp_engine_t *e, double *psi, double *msg_out) {
@@ -1434,14 +1443,14 @@ int sbmbp_shard_sweep_chunk(sbmbp_engine_t *e, uint32_t j, uint32_t c) {
         HIPCHK(hipEventRecord(e0, e->stream));
     }
     if (nb)
-        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ>), dim3(nb), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr, Mio,
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false>), dim3(nb), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr, Mio,
                                             psi_old, psi_new, e->d_blk_row + b0, e->d_blk_e0 + b0, e->d_P, int(e->dc),
-                                            e->d_partials + size_t(b0) * (e->Q + 1)));
+                                            e->d_partials + size_t(b0) * (e->Q + 1), (const int32_t *)nullptr));
     if (e->timing && nb) HIPCHK(hipEventRecord(e1, e->stream));
     if (nh)
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi_hub<QQ>), dim3(nh), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
                                             e->d_nbr, Mio, psi_old, psi_new, e->d_hub_row + h0, e->d_hub_blk + h0, e->d_P,
-                                            int(e->dc), e->d_partials));
+                                            int(e->dc), e->d_partials, (const int32_t *)nullptr));
     HIPCHK(hipGetLastError());
     return SBMBP_OK;
 }

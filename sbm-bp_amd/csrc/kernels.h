@@ -602,7 +602,10 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
 // difference the reference's criterion uses is measured by k_msg_diff before convergence is declared
 // (so a period-2 oscillation, whose 2-step difference vanishes, can never pass as converged).
 // ------------------------------------------------------------------------------------------------
-template <int Q>
+// CLAMP: rows with clamp[i] != -1 (bp_conditional, bp.cpp:1100-1126) keep their marginal and out-messages. Their state is
+// one-hot (-i 1 / -f), and for a one-hot neighbour the reconstruction psi_l / (W^T m) normalises to that same one-hot
+// vector exactly, so clamped rows need no special case on the receiving side.
+template <int Q, bool CLAMP>
 __global__ void
 #if SBMBP_PSI_WAVES > 0
 __launch_bounds__(FTPB, SBMBP_PSI_WAVES)
@@ -611,7 +614,8 @@ __launch_bounds__(FTPB)
 #endif
 k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, double *__restrict__ Mio,
             const double *__restrict__ psi_old, double *__restrict__ psi_new, const uint32_t *__restrict__ blk_row,
-            const uint32_t *__restrict__ blk_e0, const dev_params *__restrict__ P, int dc, double *__restrict__ partials) {
+            const uint32_t *__restrict__ blk_e0, const dev_params *__restrict__ P, int dc, double *__restrict__ partials,
+            const int32_t *__restrict__ clamp) {
     constexpr int EPT = frame_cfg<Q>::EPT, CAP = frame_cfg<Q>::CAP, RCAP = frame_cfg<Q>::RCAP;
     __shared__ double sb[CAP * Q];
     __shared__ double sA[RCAP * Q];
@@ -619,6 +623,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     __shared__ uint16_t srow[CAP];
     __shared__ double sred[FWAVES * (Q + 1)];
     __shared__ int sbig;  // the segment holds a row above BIG_ROW edges
+    __shared__ uint8_t sfl[CLAMP ? RCAP : 1];  // 1 = clamped row
 
     // Segment bounds (row range and edge range side by side) and the stop flag come from one level of scalar
     // loads, so the streams are issued at once; the row offsets -> LDS fill, which only the later phases need,
@@ -659,6 +664,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
         const int es = int(srp[r]), ee = int(srp[r + 1]);
         if (ee - es > BIG_ROW) sbig = 1;
         for (int e = es; e < ee; ++e) srow[e] = uint16_t(r);
+        if (CLAMP) sfl[r] = clamp[r0 + r] != -1 ? 1 : 0;
     }
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
@@ -703,7 +709,14 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     };
     for (int r = tid; r < nrows; r += FTPB) {
         const int es = int(srp[r]), ee = int(srp[r + 1]);
-        if (ee - es <= BIG_ROW) {
+        if (CLAMP && sfl[r]) {
+            double pv[Q];
+            load_vec<Q>(psi_old + size_t(r0 + r) * Q, pv);
+            store_vec<Q>(psi_new + size_t(r0 + r) * Q, pv);
+            const double gi = dc ? double(ee - es) : 1.0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) Sacc[q] += gi * pv[q];
+        } else if (ee - es <= BIG_ROW) {
             double A[Q];
 #pragma unroll
             for (int q = 0; q < Q; ++q) A[q] = 1.0;
@@ -720,7 +733,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     if (sbig)  // uniform: written before the barrier that ends phase 1
     for (int r = tid >> 6; r < nrows; r += FWAVES) {  // wave-uniform row index
         const int es = int(srp[r]), ee = int(srp[r + 1]);
-        if (ee - es > BIG_ROW) {
+        if (ee - es > BIG_ROW && !(CLAMP && sfl[r])) {
             double A[Q];
             int ae[Q];
             row_product_wave<Q>(sb, es, ee, A, ae);
@@ -733,7 +746,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
         const int le = j * FTPB + tid;
-        if (le < ne) {
+        if (le < ne && !(CLAMP && sfl[srow[le]])) {
             const int r = srow[le];
             double A[Q], b[Q], cav[Q], out[Q];
             load_vec<Q>(&sA[r * Q], A);
@@ -759,7 +772,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_sweep_psi_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, double *__restrict__ Mio,
                 const double *__restrict__ psi_old, double *__restrict__ psi_new, const uint32_t *__restrict__ hub_row,
                 const uint32_t *__restrict__ hub_blk, const dev_params *__restrict__ P, int dc,
-                double *__restrict__ partials) {
+                double *__restrict__ partials, const int32_t *__restrict__ clamp) {
     if (P->stop) return;
     __shared__ double sAq[BLOCK * Q];
     __shared__ int sEq[BLOCK * Q];
@@ -772,6 +785,17 @@ k_sweep_psi_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict
 #pragma unroll
     for (int q = 0; q < Q; ++q) Sacc[q] = 0.0;
     double md = 0.0;
+    if (clamp != nullptr && clamp[i] != -1) {  // clamped hub (uniform): marginal copied, messages stay
+        if (tid == 0) {
+            double pv[Q];
+            load_vec<Q>(psi_old + size_t(i) * Q, pv);
+            store_vec<Q>(psi_new + size_t(i) * Q, pv);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) Sacc[q] = (dc ? di : 1.0) * pv[q];
+        }
+        block_reduce_store<Q>(Sacc, md, sred, partials + size_t(hub_blk[blockIdx.x]) * (Q + 1));
+        return;
+    }
     double A[Q];
     int ae[Q];
 #pragma unroll

@@ -402,3 +402,23 @@ def test_q8_learning_follows_the_synchronous_oracle(S, orc):
     assert res.em_steps == steps and list(na1) == list(ona)
     assert np.abs(cab - ocab).max() < 1e-6 * np.abs(ocab).max() and abs(res.free_energy - f) < 1e-8
     assert res.overlap > 0.9
+
+
+def test_clamped_rows_run_in_the_marginal_gather_form(S, orc):
+    """-i 1 (bp_conditional with one-hot clamped rows): after the first explicit sweep the engine uses the marginal-gather
+    kernel and still follows the oracle's synchronous sweeps; an arbitrary state (set_state) falls back to message gather"""
+    a = args_of(golden("c1_planted_i1_seed0"))
+    _, _, bp, _ = engine_from(S, a)
+    _, obp, _ = oracle_from(orc, a)
+    for _ in range(5):
+        assert abs(bp.sweep(1, 1.0) - obp.sweep_sync(1.0)) < 1e-12
+    psi, msg = bp.get_state()
+    opsi, omsg = obp.get_state()
+    assert np.abs(psi - opsi).max() < 1e-12 and np.abs(msg - omsg).max() < 1e-12
+    assert bp.stats().psi_form_sweeps == 4
+    clamped = np.flatnonzero(np.asarray(a["beliefs"]) != -1)
+    assert (psi[clamped].max(1) == 1.0).all()  # untouched one-hot marginals
+    bp.set_state(psi, msg)
+    before = bp.stats().psi_form_sweeps
+    bp.sweep(3, 1.0)
+    assert bp.stats().psi_form_sweeps == before
