@@ -32,6 +32,8 @@ WORKLOADS = {
     "C2": (1_000_000, 2, 3.0, 0.1, 0, 1),
     "C5": (1_000_000, 4, 5.0, 0.1, 0, 4),
     "small": (200_000, 4, 10.0, 0.1, 0, 9),
+    # ten times C3 on one GPU (E2 = 1e9 < 2^32; ~63 GB of the 288 GB): not a SURVEY configuration, a capacity check
+    "C3x10": (100_000_000, 4, 10.0, 0.1, 0, 2),
     # degree-corrected SBM, power-law propensities, --deg_corr_flag 1 (hub rows take the workgroup-per-row kernel)
     "C4": (1_000_000, 8, 8.0, 0.1, 1, 3),
 }
