@@ -31,7 +31,7 @@ cab, na = synth.cab_matrix(Q, cin, cout), np.array(synth.group_sizes(N, Q), dtyp
 
 def run(w):
     t = time.perf_counter()
-    sb = ShardedBP.from_csr(row_ptr, nbr, Q, dc, LocalComm(w), n_chunks=4 if w > 1 else 1)
+    sb = ShardedBP.from_csr(row_ptr, nbr, Q, dc, LocalComm(w), n_chunks=int(os.environ.get("SBMBP_SHARD_CHUNKS", "4")) if w > 1 else 1)
     sb.init_messages_device(1234, tc)
     sb.expand_bp_params(cab, na, 1.0)
     print("world %d: plans + shards in %.1f s" % (w, time.perf_counter() - t), flush=True)
