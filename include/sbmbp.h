@@ -229,6 +229,14 @@ int sbmbp_shard_pack(sbmbp_engine_t *e, uint32_t j, const uint32_t *d_idx, uint3
 /* expand n received (staged) rows of ncomp components into the halo rows d_halo_row[0..n) (each < n_halo) of the
  * table sweep j reads */
 int sbmbp_shard_unpack(sbmbp_engine_t *e, uint32_t j, const double *d_in, const uint32_t *d_halo_row, uint32_t n, uint32_t ncomp);
+/* Fused exchange buffers (optional; without this call every sweep needs sbmbp_shard_pack before and sbmbp_shard_unpack
+ * after the exchange). snd_ptr[n_own+1] / snd_slot[snd_ptr[n_own]] (host, copied): the rows of d_sendbuf (ncomp
+ * components each) that ship the marginal of every own row. d_stage0/1: receive buffers of halo table 0/1, n_halo rows of
+ * ncomp components in halo order. With them sbmbp_shard_sweep_chunk writes each new marginal of the chunk into its send
+ * slots and gathers halo marginals of the table it reads from the matching receive buffer; the halo ROWS of the marginal
+ * tables are then only refreshed by sbmbp_shard_unpack (needed before the reductions, not between sweeps). */
+int sbmbp_shard_set_io(sbmbp_engine_t *e, const uint32_t *snd_ptr, const uint32_t *snd_slot, double *d_sendbuf,
+                       const double *d_stage0, const double *d_stage1, uint32_t ncomp);
 /* which of the two marginal buffers sweep j reads (0/1); the other one is written */
 int sbmbp_shard_read_buffer(sbmbp_engine_t *e, uint32_t j);
 /* red[0..Q) = sum over owned rows of g_i psi_i of the buffer sweep j reads (field initialisation) */

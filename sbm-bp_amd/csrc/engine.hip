@@ -46,6 +46,10 @@ struct sbmbp_engine {
     uint64_t edge0 = 0;
     double *d_red = nullptr;  // caller-owned reduction hand-off buffer (shards)
     double *d_Min = nullptr;  // shards: materialised incoming messages for the reductions (allocated on first use)
+    uint32_t *d_snd_ptr = nullptr, *d_snd_slot = nullptr;  // shards: fused exchange buffers (sbmbp_shard_set_io)
+    double *io_sendbuf = nullptr;
+    const double *io_stage[2] = {nullptr, nullptr};
+    uint32_t io_ncomp = 0;
     std::vector<uint32_t> chunk_blk, chunk_hub;  // per row chunk: first segment / first hub row (n_chunks+1 entries)
     // graph + work decomposition in HBM
     uint32_t *d_row_ptr = nullptr, *d_rev = nullptr, *d_nbr = nullptr, *d_src = nullptr;
@@ -226,7 +230,7 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form) {
         if (e->n_hub && psi_form) {
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi_hub<QQ>), dim3(e->n_hub), dim3(BLOCK), 0, hs, e->d_row_ptr,
                                                 e->d_nbr, Mnew, psi_old, psi_new, e->d_hub_row, e->d_hub_blk, e->d_P,
-                                                int(e->dc), e->d_partials, clamp));
+                                                int(e->dc), e->d_partials, clamp, shard_io{}));
         } else if (e->n_hub) {
             if (e->dc == 2) {
                 DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, hs,
@@ -253,12 +257,12 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form) {
     }
     if (psi_form) {
         if (clamp) {
-            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, true>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
-                                                Mnew, psi_old, psi_new, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), e->d_partials, clamp));
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, true, false>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
+                                                Mnew, psi_old, psi_new, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), e->d_partials, clamp, shard_io{}));
         } else {
-            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, false>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
                                                 Mnew, psi_old, psi_new, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), e->d_partials,
-                                                (const int32_t *)nullptr));
+                                                (const int32_t *)nullptr, shard_io{}));
         }
     } else if (e->dc == 2) {
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, true>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
@@ -899,7 +903,7 @@ void sbmbp_destroy(sbmbp_engine_t *e) {
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->ext_psi) e->d_psi[0] = e->d_psi[1] = nullptr;  // caller-owned
     void *ptrs[] = {e->d_row_ptr, e->d_rev, e->d_nbr, e->d_src, e->d_blk_row, e->d_blk_e0, e->d_hub_row, e->d_hub_blk, e->d_true,
-                    e->d_clamp, e->d_M[0], e->d_M[1], e->d_psi[0], e->d_psi[1], e->d_Min, e->d_P, e->d_partials, e->d_small, e->d_hist, e->d_mats,
+                    e->d_clamp, e->d_M[0], e->d_M[1], e->d_psi[0], e->d_psi[1], e->d_Min, e->d_snd_ptr, e->d_snd_slot, e->d_P, e->d_partials, e->d_small, e->d_hist, e->d_mats,
                     e->d_stage};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto ev : e->ev) hipEventDestroy(ev);
@@ -1386,6 +1390,26 @@ int sbmbp_shard_begin(sbmbp_engine_t *e, double armed_crit) {
 
 int sbmbp_shard_read_buffer(sbmbp_engine_t *e, uint32_t j) { return (e && e->sharded) ? ((e->pcur + int(j)) & 1) : SBMBP_ERR_ARG; }
 
+int sbmbp_shard_set_io(sbmbp_engine_t *e, const uint32_t *snd_ptr, const uint32_t *snd_slot, double *d_sendbuf,
+                       const double *d_stage0, const double *d_stage1, uint32_t ncomp) {
+    IS_SHARD(e);
+    if (!snd_ptr || (ncomp != e->Q && ncomp + 1 != e->Q)) return SBMBP_ERR_ARG;
+    const uint32_t n_slots = snd_ptr[e->N];
+    if ((n_slots && (!snd_slot || !d_sendbuf)) || (e->n_halo && (!d_stage0 || !d_stage1))) return SBMBP_ERR_ARG;
+    if (e->d_snd_ptr) { hipFree(e->d_snd_ptr); e->d_snd_ptr = nullptr; }
+    if (e->d_snd_slot) { hipFree(e->d_snd_slot); e->d_snd_slot = nullptr; }
+    CHK(dev_alloc(e, &e->d_snd_ptr, size_t(e->N) + 1));
+    CHK(dev_alloc(e, &e->d_snd_slot, std::max<size_t>(1, n_slots)));
+    HIPCHK(hipMemcpyAsync(e->d_snd_ptr, snd_ptr, (size_t(e->N) + 1) * 4, hipMemcpyHostToDevice, e->stream));
+    if (n_slots) HIPCHK(hipMemcpyAsync(e->d_snd_slot, snd_slot, size_t(n_slots) * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->io_sendbuf = d_sendbuf;
+    e->io_stage[0] = d_stage0;
+    e->io_stage[1] = d_stage1;
+    e->io_ncomp = ncomp;
+    return SBMBP_OK;
+}
+
 int sbmbp_shard_pack(sbmbp_engine_t *e, uint32_t j, const uint32_t *d_idx, uint32_t n, double *d_out, uint32_t ncomp) {
     IS_SHARD(e);
     if (ncomp != e->Q && ncomp + 1 != e->Q) return SBMBP_ERR_ARG;
@@ -1428,6 +1452,16 @@ int sbmbp_shard_sweep_chunk(sbmbp_engine_t *e, uint32_t j, uint32_t c) {
     double *Mio = e->d_M[mc ^ 1];
     const double *psi_old = e->d_psi[pc];
     double *psi_new = e->d_psi[pc ^ 1];
+    shard_io io;
+    std::memset(&io, 0, sizeof io);
+    if (e->d_snd_ptr) {  // fused exchange buffers: gather the halo of table pc from its receive buffer, drop new marginals into the send slots
+        io.snd_ptr = e->d_snd_ptr;
+        io.snd_slot = e->d_snd_slot;
+        io.sendbuf = e->io_sendbuf;
+        io.halo_stage = e->io_stage[pc];
+        io.n_own = e->N;
+        io.ncomp = int(e->io_ncomp);
+    }
     CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (e->Q + 1)));
     const uint32_t b0 = e->chunk_blk[c], nb = e->chunk_blk[c + 1] - b0;
     const uint32_t h0 = e->chunk_hub[c], nh = e->chunk_hub[c + 1] - h0;
@@ -1443,14 +1477,22 @@ int sbmbp_shard_sweep_chunk(sbmbp_engine_t *e, uint32_t j, uint32_t c) {
         HIPCHK(hipEventRecord(e0, e->stream));
     }
     if (nb)
-        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false>), dim3(nb), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr, Mio,
-                                            psi_old, psi_new, e->d_blk_row + b0, e->d_blk_e0 + b0, e->d_P, int(e->dc),
-                                            e->d_partials + size_t(b0) * (e->Q + 1), (const int32_t *)nullptr));
+    {
+        if (io.snd_ptr) {
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, true>), dim3(nb), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr, Mio,
+                                                psi_old, psi_new, e->d_blk_row + b0, e->d_blk_e0 + b0, e->d_P, int(e->dc),
+                                                e->d_partials + size_t(b0) * (e->Q + 1), (const int32_t *)nullptr, io));
+        } else {
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, false>), dim3(nb), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr, Mio,
+                                                psi_old, psi_new, e->d_blk_row + b0, e->d_blk_e0 + b0, e->d_P, int(e->dc),
+                                                e->d_partials + size_t(b0) * (e->Q + 1), (const int32_t *)nullptr, io));
+        }
+    }
     if (e->timing && nb) HIPCHK(hipEventRecord(e1, e->stream));
     if (nh)
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi_hub<QQ>), dim3(nh), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
                                             e->d_nbr, Mio, psi_old, psi_new, e->d_hub_row + h0, e->d_hub_blk + h0, e->d_P,
-                                            int(e->dc), e->d_partials, (const int32_t *)nullptr));
+                                            int(e->dc), e->d_partials, (const int32_t *)nullptr, io));
     HIPCHK(hipGetLastError());
     return SBMBP_OK;
 }

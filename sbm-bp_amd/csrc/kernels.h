@@ -602,10 +602,33 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
 // difference the reference's criterion uses is measured by k_msg_diff before convergence is declared
 // (so a period-2 oscillation, whose 2-step difference vanishes, can never pass as converged).
 // ------------------------------------------------------------------------------------------------
+// Shard mode of the marginal-gather sweep: halo marginals are gathered straight from the receive buffer the exchange
+// filled (rows of ncomp = Q-1 or Q components; the halo is numbered in receive order, plan.py), and a freshly computed
+// marginal is dropped into every send slot that ships it, so the sweep needs no pack and no unpack kernel around it.
+struct shard_io {
+    const uint32_t *snd_ptr;   // [n_own + 1] send slots of every own row (CSR)
+    const uint32_t *snd_slot;
+    double *sendbuf;           // rows of ncomp components, ordered (chunk, peer, row)
+    const double *halo_stage;  // received halo rows of the table this sweep reads
+    uint32_t n_own;
+    int ncomp;
+};
+template <int Q> __device__ __forceinline__ void load_halo_row(const shard_io &io, uint32_t h, double (&v)[Q]) {
+    if (io.ncomp == Q) load_vec<Q>(io.halo_stage + size_t(h) * Q, v);
+    else load_msg<Q>(io.halo_stage, h, v);  // Q-1 components; the last is max(0, 1 - sum), as k_unpack_rows restores it
+}
+template <int Q> __device__ __forceinline__ void send_row(const shard_io &io, uint32_t i, const double (&pv)[Q]) {
+    for (uint32_t s = io.snd_ptr[i]; s < io.snd_ptr[i + 1]; ++s) {
+        double *dst = io.sendbuf + size_t(io.snd_slot[s]) * io.ncomp;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) if (q < io.ncomp) dst[q] = pv[q];
+    }
+}
+
 // CLAMP: rows with clamp[i] != -1 (bp_conditional, bp.cpp:1100-1126) keep their marginal and out-messages. Their state is
 // one-hot (-i 1 / -f), and for a one-hot neighbour the reconstruction psi_l / (W^T m) normalises to that same one-hot
 // vector exactly, so clamped rows need no special case on the receiving side.
-template <int Q, bool CLAMP>
+template <int Q, bool CLAMP, bool SHARD>
 __global__ void
 #if SBMBP_PSI_WAVES > 0
 __launch_bounds__(FTPB, SBMBP_PSI_WAVES)
@@ -615,7 +638,7 @@ __launch_bounds__(FTPB)
 k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, double *__restrict__ Mio,
             const double *__restrict__ psi_old, double *__restrict__ psi_new, const uint32_t *__restrict__ blk_row,
             const uint32_t *__restrict__ blk_e0, const dev_params *__restrict__ P, int dc, double *__restrict__ partials,
-            const int32_t *__restrict__ clamp) {
+            const int32_t *__restrict__ clamp, shard_io io) {
     constexpr int EPT = frame_cfg<Q>::EPT, CAP = frame_cfg<Q>::CAP, RCAP = frame_cfg<Q>::RCAP;
     __shared__ double sb[CAP * Q];
     __shared__ double sA[RCAP * Q];
@@ -624,6 +647,10 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     __shared__ double sred[FWAVES * (Q + 1)];
     __shared__ int sbig;  // the segment holds a row above BIG_ROW edges
     __shared__ uint8_t sfl[CLAMP ? RCAP : 1];  // 1 = clamped row
+    constexpr int SLOTS = SHARD ? 4 * RCAP : 1;          // send slots of the segment's rows kept in LDS (the rest from HBM)
+    __shared__ uint32_t ssp[SHARD ? RCAP + 1 : 1];       // send-slot offsets of the rows, relative to the segment
+    __shared__ uint32_t sslot[SLOTS];
+    __shared__ uint16_t ssrow[SLOTS];                    // row (within the segment) of every send slot
 
     // Segment bounds (row range and edge range side by side) and the stop flag come from one level of scalar
     // loads, so the streams are issued at once; the row offsets -> LDS fill, which only the later phases need,
@@ -650,16 +677,49 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     for (int j = 0; j < EPT; ++j) nl[j] = load_idx_stream(nbr + kk[j]);
 #pragma unroll
     for (int j = 0; j < EPT; ++j) load_msg_stream<Q>(Mio, kk[j], mo[j]);
-    uint32_t rpv[RPT];
+    uint32_t rpv[RPT], spv[RPT];
 #pragma unroll
     for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; rpv[t] = row_ptr[r0 + uint32_t(r < nrows ? r : nrows)]; }
+    if (SHARD) {  // the rows' send-slot offsets travel with the row offsets; the slots themselves follow after the barrier
+#pragma unroll
+        for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; spv[t] = io.snd_ptr[r0 + uint32_t(r < nrows ? r : nrows)]; }
+    }
     double pl[EPT][Q];
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) load_vec<Q>(psi_old + size_t(nl[j]) * Q, pl[j]);
+    for (int j = 0; j < EPT; ++j) {
+        if (SHARD) {
+            // one load sequence for own and halo rows: base and stride are selected, Q-1 components are loaded, the last
+            // one is loaded (own rows, full-width halo rows) or restored as max(0, 1 - sum)
+#ifdef SBMBP_DEBUG_NOSTAGE
+            const bool halo = false;
+#else
+            const bool halo = nl[j] >= io.n_own;
+#endif
+            const bool full = !halo || io.ncomp == Q;
+            const double *src = halo ? io.halo_stage + size_t(nl[j] - io.n_own) * io.ncomp : psi_old + size_t(nl[j]) * Q;
+#pragma unroll
+            for (int q = 0; q < Q - 1; ++q) pl[j][q] = src[q];
+            const double lastv = src[full ? Q - 1 : 0];
+            finish_msg<Q>(pl[j]);
+            if (full) pl[j][Q - 1] = lastv;
+        } else {
+            load_vec<Q>(psi_old + size_t(nl[j]) * Q, pl[j]);
+        }
+    }
     if (tid == 0) sbig = 0;
 #pragma unroll
     for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; if (r <= nrows) srp[r] = rpv[t] - e0; }
-    __syncthreads();  // srp visible
+    uint32_t s0 = 0;
+    if (SHARD) {
+        s0 = io.snd_ptr[r0];
+#pragma unroll
+        for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; if (r <= nrows) ssp[r] = spv[t] - s0; }
+    }
+    __syncthreads();  // srp (and ssp) visible
+    if (SHARD) {  // issue the slot loads now; they are consumed after the next barriers
+        const uint32_t ns = min(ssp[nrows], uint32_t(SLOTS));
+        for (uint32_t x = tid; x < ns; x += FTPB) sslot[x] = io.snd_slot[s0 + x];
+    }
     for (int r = tid; r < nrows; r += FTPB) {
         const int es = int(srp[r]), ee = int(srp[r + 1]);
         if (ee - es > BIG_ROW) sbig = 1;
@@ -700,12 +760,28 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
         } else {
             tot = apply_field<Q>(P, dc, di, A);
         }
-        store_vec<Q>(&sA[r * Q], A);
+        if (!SHARD) store_vec<Q>(&sA[r * Q], A);
         const double inv = 1.0 / tot;
         const double gi = dc ? di : 1.0;
 #pragma unroll
         for (int q = 0; q < Q; ++q) { pv[q] = A[q] * inv; Sacc[q] += gi * pv[q]; }
         store_vec<Q>(psi_new + size_t(r0 + r) * Q, pv);
+        if (SHARD) {
+            // phase 3 only needs the row vector up to a factor, so LDS gets the normalised marginal: the send pass below
+            // (one lane per send slot, after the barrier) copies it from there
+            store_vec<Q>(&sA[r * Q], pv);
+#ifndef SBMBP_DEBUG_NOSEND
+            for (uint32_t x = ssp[r]; x < ssp[r + 1]; ++x) {
+                if (x < uint32_t(SLOTS)) {
+                    ssrow[x] = uint16_t(r);
+                } else {  // more slots than the LDS list holds: ship this one from here
+                    double *dst = io.sendbuf + size_t(io.snd_slot[s0 + x]) * io.ncomp;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) if (q < io.ncomp) dst[q] = pv[q];
+                }
+            }
+#endif
+        }
     };
     for (int r = tid; r < nrows; r += FTPB) {
         const int es = int(srp[r]), ee = int(srp[r + 1]);
@@ -741,6 +817,17 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
         }
     }
     __syncthreads();
+#ifndef SBMBP_DEBUG_NOSEND
+    if (SHARD) {  // send pass: one lane per send slot, stores in flight while phase 3 runs
+        const uint32_t ns = min(ssp[nrows], uint32_t(SLOTS));
+        for (uint32_t x = tid; x < ns; x += FTPB) {
+            const double *src = &sA[int(ssrow[x]) * Q];
+            double *dst = io.sendbuf + size_t(sslot[x]) * io.ncomp;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) if (q < io.ncomp) dst[q] = src[q];
+        }
+    }
+#endif
 
     // ---- phase 3: lane per directed edge: cavity, normalise, overwrite own slot
 #pragma unroll
@@ -772,7 +859,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_sweep_psi_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, double *__restrict__ Mio,
                 const double *__restrict__ psi_old, double *__restrict__ psi_new, const uint32_t *__restrict__ hub_row,
                 const uint32_t *__restrict__ hub_blk, const dev_params *__restrict__ P, int dc,
-                double *__restrict__ partials, const int32_t *__restrict__ clamp) {
+                double *__restrict__ partials, const int32_t *__restrict__ clamp, shard_io io) {
     if (P->stop) return;
     __shared__ double sAq[BLOCK * Q];
     __shared__ int sEq[BLOCK * Q];
@@ -802,7 +889,9 @@ k_sweep_psi_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict
     for (int q = 0; q < Q; ++q) { A[q] = 1.0; ae[q] = 0; }
     auto incoming_field = [&](uint32_t le, double (&mo)[Q], double (&b)[Q]) {
         double pl[Q], bo[Q], inc[Q];
-        load_vec<Q>(psi_old + size_t(nbr[e0 + le]) * Q, pl);
+        const uint32_t l = nbr[e0 + le];
+        if (io.halo_stage != nullptr && l >= io.n_own) load_halo_row<Q>(io, l - io.n_own, pl);
+        else load_vec<Q>(psi_old + size_t(l) * Q, pl);
         load_msg<Q>(Mio, size_t(e0 + le), mo);
         edge_field<Q, false>(P, mo, 0.0, bo);
         double tot = 0.0;
@@ -828,6 +917,7 @@ k_sweep_psi_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict
 #pragma unroll
         for (int q = 0; q < Q; ++q) { pv[q] = A[q] * inv; Sacc[q] = (dc ? di : 1.0) * pv[q]; }
         store_vec<Q>(psi_new + size_t(i) * Q, pv);
+        if (io.snd_ptr != nullptr) send_row<Q>(io, i, pv);
     }
     for (uint32_t le = tid; le < d; le += BLOCK) {
         double mo[Q], b[Q], out[Q], cav[Q];

@@ -52,11 +52,13 @@ class HipShardBackend:
         self.red = torch.zeros(8192, dtype=torch.float64, device=self.device)
         self.send_idx = torch.as_tensor(plan.send_idx_chunked.astype(np.int32), device=self.device)
         self.sendbuf = torch.zeros((max(1, len(plan.send_idx_chunked)), self.ncomp), dtype=torch.float64, device=self.device)
-        # receive staging buffer, ordered by (chunk, peer); unpack scatters staged rows to their halo rows
-        self.recvbuf = torch.zeros((max(1, plan.n_halo), self.ncomp), dtype=torch.float64, device=self.device)
+        # one receive buffer per marginal table (the exchange for table t+1 runs while the sweep reads the buffer of table
+        # t), rows in halo order = (chunk, peer, id): a chunk's exchange fills one contiguous slice
+        self.recvbuf = torch.zeros((2, max(1, plan.n_halo), self.ncomp), dtype=torch.float64, device=self.device)
         self.stage_to_halo = torch.as_tensor(plan.stage_to_halo.astype(np.int32), device=self.device)
         self.send_views = [self.sendbuf[int(plan.send_off_c[c]):int(plan.send_off_c[c + 1])] for c in range(plan.n_chunks)]
-        self.recv_views = [self.recvbuf[int(plan.stage_off_c[c]):int(plan.stage_off_c[c + 1])] for c in range(plan.n_chunks)]
+        self._recv_views = [[self.recvbuf[t][int(plan.stage_off_c[c]):int(plan.stage_off_c[c + 1])] for c in range(plan.n_chunks)]
+                            for t in (0, 1)]
         self._row_ptr = np.ascontiguousarray(plan.row_ptr, dtype=np.uint64)
         self._nbr = np.ascontiguousarray(plan.nbr_local, dtype=np.uint32)
         self._chunk_row = np.ascontiguousarray(plan.chunk_row, dtype=np.uint32)
@@ -69,6 +71,17 @@ class HipShardBackend:
         self._h = h
         # run on torch's current stream so kernels and collectives are ordered without host syncs
         self._check(self._lib.sbmbp_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        # fused exchange buffers: the sweep kernel fills the send buffer and reads the halo from the receive buffers, so no
+        # pack / unpack kernel runs between sweeps (SBMBP_SHARD_FUSED=0: the separate kernels, for A/B runs)
+        self.fused = os.environ.get("SBMBP_SHARD_FUSED", "1") != "0"
+        if self.fused:
+            self._snd_ptr = np.ascontiguousarray(plan.snd_ptr, dtype=np.uint32)
+            self._snd_slot = np.ascontiguousarray(plan.snd_slot, dtype=np.uint32)
+            dp = C.POINTER(C.c_double)
+            self._check(self._lib.sbmbp_shard_set_io(self._h, self._snd_ptr.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                     self._snd_slot.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                     C.cast(self.sendbuf.data_ptr(), dp), C.cast(self.recvbuf[0].data_ptr(), dp),
+                                                     C.cast(self.recvbuf[1].data_ptr(), dp), self.ncomp))
 
     def __del__(self):
         try:
@@ -102,10 +115,14 @@ class HipShardBackend:
                                                    C.cast(self.sendbuf.data_ptr() + 8 * self.ncomp * off, C.POINTER(C.c_double)),
                                                    self.ncomp))
 
+    def recv_view(self, j, c):
+        """where chunk c of the halo of the table sweep j reads is received"""
+        return self._recv_views[self.read_buffer(j)][c]
+
     def unpack(self, j):
-        """expand the staged halo rows into the table sweep j reads"""
+        """expand the received halo rows into the halo rows of the table sweep j reads"""
         if self.plan.n_halo:
-            self._check(self._lib.sbmbp_shard_unpack(self._h, j, C.cast(self.recvbuf.data_ptr(), C.POINTER(C.c_double)),
+            self._check(self._lib.sbmbp_shard_unpack(self._h, j, C.cast(self.recvbuf[self.read_buffer(j)].data_ptr(), C.POINTER(C.c_double)),
                                                      C.cast(self.stage_to_halo.data_ptr(), C.POINTER(C.c_uint32)),
                                                      self.plan.n_halo, self.ncomp))
 
@@ -311,6 +328,7 @@ class ShardedBP:
             compress = os.environ.get("SBMBP_HALO_COMPRESS", "1") != "0"  # Q-1 components on the wire (default) or all Q
             backend_factory = lambda plan: HipShardBackend(plan, Q, dc, dev, compress=compress)  # noqa: E731
         self.shards = [backend_factory(p) for p in plans]
+        self.fused = all(getattr(sh, "fused", False) for sh in self.shards)
         self.N_global = plans[0].n_global
         self.E2_local = sum(p.n_edges for p in plans)
         self.E2_global = None
@@ -396,12 +414,13 @@ class ShardedBP:
             sh.set_params(self.cab, self.na, self.beta)
 
     # -- one sweep = exchange, local sweep, reduce, finalize ------------------------------------
-    def _exchange_chunk(self, j, c):
-        """ship the chunk-c boundary marginals of the table that sweep j reads: pack, then ONE all-to-all-v of
-        contiguous slices (send buffer and receive staging buffer are ordered by (chunk, peer))"""
-        for sh in self.shards:
-            sh.pack(j, c)
-        return self.comm.exchange([sh.recv_views[c] for sh in self.shards], [sh.send_views[c] for sh in self.shards],
+    def _exchange_chunk(self, j, c, packed=False):
+        """ship the chunk-c boundary marginals of the table that sweep j reads: ONE all-to-all-v of contiguous slices (send
+        buffer and receive buffer are ordered by (chunk, peer)). packed: the sweep kernel already filled the send buffer."""
+        if not packed:
+            for sh in self.shards:
+                sh.pack(j, c)
+        return self.comm.exchange([sh.recv_view(j, c) for sh in self.shards], [sh.send_views[c] for sh in self.shards],
                                   [p.recv_counts_cp[c] for p in self.plans], [p.send_counts_cp[c] for p in self.plans])
 
     def _reduce(self, n_sum, n_max):
@@ -421,14 +440,16 @@ class ShardedBP:
         """sweep j reads a table whose halo is already in place (shipped during sweep j-1 or by _begin);
         the new marginals of chunk c travel while chunk c+1 is swept"""
         works = []
+        fused = self.fused
         for c in range(self.plans[0].n_chunks):
             for sh in self.shards:
                 sh.sweep_chunk(j, c)
-            works += self._exchange_chunk(j + 1, c)
+            works += self._exchange_chunk(j + 1, c, packed=fused)
         for w in works:
             w.wait()
         for sh in self.shards:
-            sh.unpack(j + 1)
+            if not fused:
+                sh.unpack(j + 1)
             sh.sweep_fold()
         self._gather_red()
         for sh in self.shards:

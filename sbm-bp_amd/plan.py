@@ -157,12 +157,29 @@ class ShardPlan:
             for c in range(Cn):
                 self.recv_counts_cp[c, p] = cut[c + 1] - cut[c]
                 self.recv_off_cp[c, p] = halo_off[p] + cut[c]
-        # receive staging buffer ordered by (chunk, peer): one contiguous slice per chunk, so a chunk's exchange is
-        # a single all_to_all_single; stage_to_halo[r] = halo row of staged row r (the unpack kernel scatters)
+        # The halo part of the table is kept in RECEIVE order, (chunk, peer, global id): what arrives for one chunk is one
+        # contiguous slice (a single all_to_all_single), and a staged row r IS halo row r - the sweep kernel can gather
+        # halo marginals straight from the receive buffer. Rename the halo entries accordingly.
         self.stage_off_c = np.concatenate([[0], np.cumsum(self.recv_counts_cp.sum(1))])
         pieces = [np.arange(self.recv_off_cp[c, p], self.recv_off_cp[c, p] + self.recv_counts_cp[c, p]) for c in range(Cn) for p in range(W)]
-        self.stage_to_halo = (np.concatenate(pieces) if pieces else np.zeros(0)).astype(np.int64)
+        by_receive = (np.concatenate(pieces) if pieces else np.zeros(0)).astype(np.int64)  # peer-major index of staged row r
+        if self.n_halo:
+            renamed = np.empty(self.n_halo, dtype=np.int64)
+            renamed[by_receive] = np.arange(self.n_halo, dtype=np.int64)
+            self.halo_global = remote[by_receive]
+            halo_edges = self.nbr_local >= self.n_own
+            self.nbr_local[halo_edges] = (self.n_own + renamed[self.nbr_local[halo_edges].astype(np.int64) - self.n_own]).astype(np.uint32)
+            off = 0
+            for c in range(Cn):
+                for p in range(W):
+                    self.recv_off_cp[c, p] = off
+                    off += int(self.recv_counts_cp[c, p])
+        self.stage_to_halo = np.arange(self.n_halo, dtype=np.int64)  # identity (kept for the unpack interface)
         self.send_off_c = np.concatenate([[0], np.cumsum(self.send_counts_cp.sum(1))])
+        # send slots of every own row (CSR): where the sweep kernel drops a freshly computed marginal for its readers
+        rows = self.send_idx_chunked.astype(np.int64)
+        self.snd_slot = np.argsort(rows, kind="stable").astype(np.uint32)
+        self.snd_ptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=self.n_own))]).astype(np.uint32)
 
     def summary(self):
         return dict(rank=self.rank, n_own=self.n_own, n_halo=self.n_halo, n_edges=self.n_edges,

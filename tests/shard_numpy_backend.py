@@ -55,6 +55,9 @@ class NumpyShardBackend:
     def read_buffer(self, j):
         return (self.pcur + j) & 1
 
+    def recv_view(self, j, c):
+        return self.recv_views[c]
+
     def pack(self, j, c):
         off, n = int(self.plan.send_off_cp[c, 0]), int(self.plan.send_counts_cp[c].sum())
         if n:

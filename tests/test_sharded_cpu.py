@@ -58,11 +58,16 @@ def test_partition_and_plan_invariants(orc):
             # the local table entry of every edge is the right global vertex
             table = np.concatenate([np.arange(p.row0, p.row0 + p.n_own), p.halo_global])
             assert (table[p.nbr_local] == g.nbr[p.edge0:p.edge0 + p.n_edges]).all()
-            for q in plans:  # what p sends to q is exactly q's halo slice owned by p, in the same order
-                s0 = int(p.send_counts[:q.rank].sum())
+            for q in plans:  # what p sends to q is exactly the part of q's halo that p owns (the halo is kept in receive
+                s0 = int(p.send_counts[:q.rank].sum())  # order, (chunk, peer, id): checked slice for slice above)
                 sent = p.row0 + p.send_idx[s0:s0 + int(p.send_counts[q.rank])]
-                h0 = int(q.recv_counts[:p.rank].sum())
-                assert (sent == q.halo_global[h0:h0 + int(q.recv_counts[p.rank])]).all()
+                owned = q.halo_global[(q.halo_global >= p.row0) & (q.halo_global < p.row0 + p.n_own)]
+                assert sorted(sent.tolist()) == sorted(owned.tolist())
+            # send slots: row i's marginal goes to exactly the slots whose send index is i
+            assert p.snd_ptr[-1] == len(p.send_idx_chunked)
+            for i in (0, p.n_own // 2, p.n_own - 1):
+                slots = p.snd_slot[p.snd_ptr[i]:p.snd_ptr[i + 1]]
+                assert (p.send_idx_chunked[slots] == i).all() and len(slots) == int((p.send_idx_chunked == i).sum())
 
 
 @pytest.mark.parametrize("world", [2, 3, 5])
