@@ -690,7 +690,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
         if (SHARD) {
             // one load sequence for own and halo rows: base and stride are selected, Q-1 components are loaded, the last
             // one is loaded (own rows, full-width halo rows) or restored as max(0, 1 - sum)
-#ifdef SBMBP_DEBUG_NOSTAGE
+#ifdef SBMBP_DEBUG_NOSTAGE  // ablation build (timing only, wrong results): every gather goes to the table
             const bool halo = false;
 #else
             const bool halo = nl[j] >= io.n_own;
@@ -770,7 +770,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
             // phase 3 only needs the row vector up to a factor, so LDS gets the normalised marginal: the send pass below
             // (one lane per send slot, after the barrier) copies it from there
             store_vec<Q>(&sA[r * Q], pv);
-#ifndef SBMBP_DEBUG_NOSEND
+#ifndef SBMBP_DEBUG_NOSEND  // (defined: ablation build without the send pass, timing only)
             for (uint32_t x = ssp[r]; x < ssp[r + 1]; ++x) {
                 if (x < uint32_t(SLOTS)) {
                     ssrow[x] = uint16_t(r);
