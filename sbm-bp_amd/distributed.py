@@ -445,15 +445,19 @@ class ShardedBP:
             for sh in self.shards:
                 sh.sweep_chunk(j, c)
             works += self._exchange_chunk(j + 1, c, packed=fused)
-        for w in works:
-            w.wait()
+        if not fused:
+            for w in works:
+                w.wait()
+            works = []
         for sh in self.shards:
             if not fused:
                 sh.unpack(j + 1)
-            sh.sweep_fold()
+            sh.sweep_fold()  # local folds overlap with the last chunk's exchange (they do not touch the halo)
         self._gather_red()
         for sh in self.shards:
             sh.finalize(0, self.comm.world)
+        for w in works:  # the next sweep reads the receive buffers: its kernels wait for the exchanges here
+            w.wait()
 
     def _begin(self, armed):
         works = []
