@@ -271,6 +271,9 @@ int sbmbp_shard_em_finish(sbmbp_engine_t *e, double *na_expect, double *nna_expe
 int sbmbp_shard_poll(sbmbp_engine_t *e, sbmbp_conv_state *out);
 /* after a poll: `executed` sweeps of the queued batch really ran; flips the buffer parities */
 int sbmbp_shard_commit(sbmbp_engine_t *e, uint32_t executed);
+/* on: the sweep chunks report the exact 1-step message difference (they read the other message buffer as well) instead
+ * of the 2-step hint, so a stop flag armed at the real criterion ends the run exactly where the reference's test does */
+int sbmbp_shard_set_exact(sbmbp_engine_t *e, int on);
 /* re-arm after a trigger whose exact check failed: clears stop, sets the threshold */
 int sbmbp_shard_rearm(sbmbp_engine_t *e, double armed_crit);
 

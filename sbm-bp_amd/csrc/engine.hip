@@ -82,6 +82,7 @@ struct sbmbp_engine {
     double beta = 1.0;
     double sum_log_didl = 0.0;  // sum over directed edges of log(d_i d_l) (dc 1 constant of f_site/f_edge)
     bool have_params = false, have_state = false, has_clamp = false, field_fresh = false;
+    bool exact_mode = false;   // marginal-gather sweeps report the exact 1-step difference (they read the other message buffer too)
     bool clamp_onehot = false;  // the clamped rows hold the one-hot state of init flag 1/3: the marginal-gather sweep stays exact
     bool w_positive = false;     // every cab entry > 0: the marginal-gather sweep is well defined
     bool psi_consistent = false; // psi == marginals of the message pair held in d_M (set by an undamped sweep)
@@ -230,7 +231,7 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form) {
         if (e->n_hub && psi_form) {
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi_hub<QQ>), dim3(e->n_hub), dim3(BLOCK), 0, hs, e->d_row_ptr,
                                                 e->d_nbr, Mnew, psi_old, psi_new, e->d_hub_row, e->d_hub_blk, e->d_P,
-                                                int(e->dc), e->d_partials, clamp, shard_io{}));
+                                                int(e->dc), e->d_partials, clamp, shard_io{}, e->exact_mode ? Mold : nullptr));
         } else if (e->n_hub) {
             if (e->dc == 2) {
                 DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, hs,
@@ -258,11 +259,12 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form) {
     if (psi_form) {
         if (clamp) {
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, true, false>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
-                                                Mnew, psi_old, psi_new, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), e->d_partials, clamp, shard_io{}));
+                                                Mnew, psi_old, psi_new, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), e->d_partials, clamp, shard_io{},
+                                                e->exact_mode ? Mold : nullptr));
         } else {
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, false>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
                                                 Mnew, psi_old, psi_new, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), e->d_partials,
-                                                (const int32_t *)nullptr, shard_io{}));
+                                                (const int32_t *)nullptr, shard_io{}, e->exact_mode ? Mold : nullptr));
         }
     } else if (e->dc == 2) {
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, true>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
@@ -377,24 +379,32 @@ int run_sweeps(sbmbp_engine *e, double crit, uint32_t max_sweeps, double damping
         if (cs.stop && crit > 0) {
             if (exact < crit) {
                 result_iter = cs.conv_iter;
-            } else {  // the hint fired early: continue one sweep at a time on the exact criterion
+            } else {
+                // The hint fired early. From here the sweeps report the exact 1-step difference themselves (they read the
+                // other message buffer as well) and the device-side stop flag works on the reference's criterion, so the
+                // run goes on in batches without a host round trip per sweep.
+                e->exact_mode = true;
                 conv_state reset{0.0, -1, cs.sweep_idx, 0, 1};
-                while (executed < max_sweeps) {
-                    HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(e->d_P) + offsetof(dev_params, maxdiff), &reset,
-                                          sizeof reset, hipMemcpyHostToDevice, e->stream));
-                    const double never = -1.0;
-                    HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(e->d_P) + offsetof(dev_params, crit), &never, 8,
-                                          hipMemcpyHostToDevice, e->stream));
-                    CHK(launch_sweep(e, 0, damping, true));
-                    CHK(read_conv_state(e, &cs));
-                    if (e->timing) CHK(collect_timing(e));
-                    commit(1);
-                    ++executed;
-                    ++n_psi;
-                    reset.sweep_idx = cs.sweep_idx;
-                    CHK(message_diff(e, &exact));
-                    if (exact < crit) { result_iter = int(executed) - 1; break; }
+                HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(e->d_P) + offsetof(dev_params, maxdiff), &reset, sizeof reset,
+                                      hipMemcpyHostToDevice, e->stream));
+                HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(e->d_P) + offsetof(dev_params, crit), &crit, 8, hipMemcpyHostToDevice,
+                                      e->stream));
+                int rc = SBMBP_OK;
+                while (executed < max_sweeps && rc == SBMBP_OK) {
+                    const uint32_t batch = std::min(batch_max, max_sweeps - executed);
+                    for (uint32_t b = 0; b < batch && rc == SBMBP_OK; ++b) rc = launch_sweep(e, b, damping, true);
+                    if (rc == SBMBP_OK) rc = read_conv_state(e, &cs);
+                    if (rc != SBMBP_OK) break;
+                    if (e->timing) rc = collect_timing(e);
+                    const uint32_t ran = uint32_t(cs.sweep_idx) - executed;
+                    commit(ran);
+                    executed += ran;
+                    n_psi += ran;
+                    exact = cs.maxdiff;
+                    if (cs.stop) { result_iter = cs.conv_iter; break; }
                 }
+                e->exact_mode = false;
+                CHK(rc);
             }
         }
     }
@@ -1450,6 +1460,7 @@ int sbmbp_shard_sweep_chunk(sbmbp_engine_t *e, uint32_t j, uint32_t c) {
     if (c + 1 >= e->chunk_blk.size()) { set_error("chunk index out of range"); return SBMBP_ERR_ARG; }
     const int mc = (e->cur + int(j)) & 1, pc = (e->pcur + int(j)) & 1;
     double *Mio = e->d_M[mc ^ 1];
+    const double *Mcmp = e->exact_mode ? e->d_M[mc] : nullptr;
     const double *psi_old = e->d_psi[pc];
     double *psi_new = e->d_psi[pc ^ 1];
     shard_io io;
@@ -1481,18 +1492,18 @@ int sbmbp_shard_sweep_chunk(sbmbp_engine_t *e, uint32_t j, uint32_t c) {
         if (io.snd_ptr) {
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, true>), dim3(nb), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr, Mio,
                                                 psi_old, psi_new, e->d_blk_row + b0, e->d_blk_e0 + b0, e->d_P, int(e->dc),
-                                                e->d_partials + size_t(b0) * (e->Q + 1), (const int32_t *)nullptr, io));
+                                                e->d_partials + size_t(b0) * (e->Q + 1), (const int32_t *)nullptr, io, Mcmp));
         } else {
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, false>), dim3(nb), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr, Mio,
                                                 psi_old, psi_new, e->d_blk_row + b0, e->d_blk_e0 + b0, e->d_P, int(e->dc),
-                                                e->d_partials + size_t(b0) * (e->Q + 1), (const int32_t *)nullptr, io));
+                                                e->d_partials + size_t(b0) * (e->Q + 1), (const int32_t *)nullptr, io, Mcmp));
         }
     }
     if (e->timing && nb) HIPCHK(hipEventRecord(e1, e->stream));
     if (nh)
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi_hub<QQ>), dim3(nh), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
                                             e->d_nbr, Mio, psi_old, psi_new, e->d_hub_row + h0, e->d_hub_blk + h0, e->d_P,
-                                            int(e->dc), e->d_partials, (const int32_t *)nullptr, io));
+                                            int(e->dc), e->d_partials, (const int32_t *)nullptr, io, Mcmp));
     HIPCHK(hipGetLastError());
     return SBMBP_OK;
 }
@@ -1565,6 +1576,12 @@ int sbmbp_shard_commit(sbmbp_engine_t *e, uint32_t executed) {
     e->pcur = (e->pcur + int(executed)) & 1;
     e->sweeps += executed;
     e->psi_sweeps += executed;
+    return SBMBP_OK;
+}
+
+int sbmbp_shard_set_exact(sbmbp_engine_t *e, int on) {
+    IS_SHARD(e);
+    e->exact_mode = on != 0;
     return SBMBP_OK;
 }
 

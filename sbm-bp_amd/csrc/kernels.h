@@ -638,7 +638,9 @@ __launch_bounds__(FTPB)
 k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, double *__restrict__ Mio,
             const double *__restrict__ psi_old, double *__restrict__ psi_new, const uint32_t *__restrict__ blk_row,
             const uint32_t *__restrict__ blk_e0, const dev_params *__restrict__ P, int dc, double *__restrict__ partials,
-            const int32_t *__restrict__ clamp, shard_io io) {
+            const int32_t *__restrict__ clamp, shard_io io,
+            const double *__restrict__ Mcmp /* null: report the 2-step difference against the own previous message;
+                                               else the other message buffer (m^t): report the exact 1-step difference */) {
     constexpr int EPT = frame_cfg<Q>::EPT, CAP = frame_cfg<Q>::CAP, RCAP = frame_cfg<Q>::RCAP;
     __shared__ double sb[CAP * Q];
     __shared__ double sA[RCAP * Q];
@@ -842,10 +844,17 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
 #pragma unroll
             for (int q = 0; q < Q; ++q) { cav[q] = A[q] / b[q]; tot += cav[q]; }
             const double inv = 1.0 / tot;
+            double ref[Q];
+            if (Mcmp != nullptr) {  // uniform
+                load_msg<Q>(Mcmp, size_t(e0 + le), ref);
+            } else {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) ref[q] = mo[j][q];
+            }
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
                 out[q] = cav[q] * inv;
-                md = nanmax(md, fabs(mo[j][q] - out[q]));
+                md = nanmax(md, fabs(ref[q] - out[q]));
             }
             store_msg_stream<Q>(Mio, size_t(e0 + le), out);
         }
@@ -859,7 +868,8 @@ __global__ void __launch_bounds__(BLOCK)
 k_sweep_psi_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, double *__restrict__ Mio,
                 const double *__restrict__ psi_old, double *__restrict__ psi_new, const uint32_t *__restrict__ hub_row,
                 const uint32_t *__restrict__ hub_blk, const dev_params *__restrict__ P, int dc,
-                double *__restrict__ partials, const int32_t *__restrict__ clamp, shard_io io) {
+                double *__restrict__ partials, const int32_t *__restrict__ clamp, shard_io io,
+                const double *__restrict__ Mcmp) {
     if (P->stop) return;
     __shared__ double sAq[BLOCK * Q];
     __shared__ int sEq[BLOCK * Q];
@@ -926,6 +936,7 @@ k_sweep_psi_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict
 #pragma unroll
         for (int q = 0; q < Q; ++q) { cav[q] = A[q] / b[q]; ct += cav[q]; }
         const double ci = 1.0 / ct;
+        if (Mcmp != nullptr) load_msg<Q>(Mcmp, size_t(e0 + le), mo);  // exact 1-step difference instead of the 2-step hint
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             out[q] = cav[q] * ci;

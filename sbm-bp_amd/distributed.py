@@ -188,6 +188,9 @@ class HipShardBackend:
     def rearm(self, armed):
         self._check(self._lib.sbmbp_shard_rearm(self._h, armed))
 
+    def set_exact(self, on):
+        self._check(self._lib.sbmbp_shard_set_exact(self._h, int(bool(on))))
+
     def get_state(self):
         from sbm_bp_amd.capi import c_dp
         psi = np.zeros((self.plan.n_own, self.Q))
@@ -503,19 +506,27 @@ class ShardedBP:
         if st is not None and st.stop and crit > 0:
             if exact < crit:
                 niter = st.conv_iter
-            else:  # hint fired early: continue on the exact criterion, one sweep at a time
+            else:
+                # the hint fired early: from here the chunks report the exact 1-step difference themselves and the stop flag
+                # is armed at the real criterion, so the run goes on in batches (no all-reduce + host check per sweep)
+                for sh in self.shards:
+                    sh.set_exact(True)
+                    sh.rearm(crit)
                 while executed < max_sweeps:
+                    batch = min(check_every, max_sweeps - executed)
+                    for b in range(batch):
+                        self._queue_sweep(b)
+                    st = [sh.poll() for sh in self.shards][0]
+                    ran = st.sweep_idx - executed
                     for sh in self.shards:
-                        sh.rearm(-1.0)
-                    self._queue_sweep(0)
-                    for sh in self.shards:
-                        sh.poll()
-                        sh.commit(1)
-                    executed += 1
-                    exact = self._exact_diff()
-                    if exact < crit:
-                        niter = executed - 1
+                        sh.commit(ran)
+                    executed += ran
+                    exact = st.maxdiff
+                    if st.stop:
+                        niter = st.conv_iter
                         break
+                for sh in self.shards:
+                    sh.set_exact(False)
         self.total_sweeps += executed
         return niter, exact
 

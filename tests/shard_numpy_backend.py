@@ -48,6 +48,9 @@ class NumpyShardBackend:
         self.armed = armed
         self.st = State()
 
+    def set_exact(self, on):
+        self.exact = bool(on)
+
     def rearm(self, armed):
         self.armed = armed
         self.st.stop, self.st.conv_iter = 0, -1
@@ -109,7 +112,8 @@ class NumpyShardBackend:
         cav = np.exp(cav - cav.max(1, keepdims=True)) if e1 > e0 else cav
         new = cav / cav.sum(1, keepdims=True) if e1 > e0 else cav
         if e1 > e0:
-            self._md = max(self._md, float(np.abs(new - Mio).max()))
+            ref = self.M[(self.cur + j) & 1][e0:e1] if getattr(self, "exact", False) else Mio  # exact 1-step difference, or the 2-step hint
+            self._md = max(self._md, float(np.abs(new - ref).max()))
         Mio[:] = new
         pnew[r0:r1] = psi_new
         g = deg.astype(np.float64) if self.dc else np.ones(r1 - r0)
