@@ -449,16 +449,31 @@ double sweep_sync(bp_t &s, double damp) {
         for (uint32_t q = 0; q < Q; ++q) s.psi[size_t(i) * Q + q] = A[q] / tot;  // psi^{t+1}; h already taken from psi^t
         for (uint32_t l = 0; l < d; ++l) {
             double csum = 0.0;
+            bool usable = true;
             for (uint32_t q = 0; q < Q; ++q) {
                 double bq = b[size_t(l) * Q + q];
                 if (bq > 0.0 && A[q] / bq < std::numeric_limits<double>::infinity()) cav[q] = A[q] / bq;
-                else {  // exact cavity product when the division is not usable
-                    double p = s.eta[q] * ((s.dc == 0) ? s.exph[q] : std::exp(-di * (s.h[q] - hmin) / s.N));
-                    for (uint32_t lx = 0; lx < d; ++lx) if (lx != l) p *= b[size_t(lx) * Q + q];
-                    cav[q] = p;
-                }
-                csum += cav[q];
+                else usable = false;
             }
+            if (!usable) {
+                // exact cavity product when a division is not usable (b == 0 with a forbidden group pair, :1029-1042). ALL
+                // components are recomputed, each with its own exponent, and finished in the log domain: mixing a quotient
+                // A[q]/b[q] (A carries an arbitrary common factor) with an unscaled product would compare different scales.
+                std::vector<double> pm(Q, 1.0), lpq(Q);
+                std::vector<int> pe(Q, 0);
+                for (uint32_t lx = 0; lx < d; ++lx) {
+                    if (lx == l) continue;
+                    for (uint32_t q = 0; q < Q; ++q) { int k; pm[q] = std::frexp(pm[q] * b[size_t(lx) * Q + q], &k); pe[q] += k; }
+                }
+                double mx = -1e300;
+                for (uint32_t q = 0; q < Q; ++q) {
+                    double g = (s.dc == 0) ? s.beta : di;
+                    lpq[q] = std::log(pm[q]) + double(pe[q]) * 0.6931471805599453 + std::log(s.eta[q]) - g * s.h[q] / s.N;
+                    mx = std::max(mx, lpq[q]);
+                }
+                for (uint32_t q = 0; q < Q; ++q) cav[q] = std::exp(lpq[q] - mx);
+            }
+            for (uint32_t q = 0; q < Q; ++q) csum += cav[q];
             for (uint32_t q = 0; q < Q; ++q) {
                 double nv = cav[q] / csum;
                 double old = s.M[(k0 + l) * Q + q];

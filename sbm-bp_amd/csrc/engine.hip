@@ -496,13 +496,14 @@ double contract(const double *Mk, uint32_t Q, unsigned k, const std::vector<cons
     return acc;
 }
 
-// highest series order whose moment tensors (Q + Q^2 + ... + Q^K doubles) fit the reduction buffers: 4 up to Q = 9, 3 above
+// highest series order whose moment tensors (Q + Q^2 + ... + Q^K doubles) fit k_moments (20 entries per thread of a
+// 256-thread workgroup = 5120) and the reduction buffers: 4 up to Q = 8, 3 above
 int max_series_order(uint32_t Q) {
     int K = 0;
     uint64_t T = 0, sz = 1;
     while (K < 4) {
         sz *= Q;
-        if (T + sz > 8000) break;
+        if (T + sz > 5120) break;
         T += sz;
         ++K;
     }
@@ -991,7 +992,7 @@ int sbmbp_init_messages(sbmbp_engine_t *e, uint32_t flag, const int32_t *conf, c
             }
             if (herr == hipSuccess) herr = hipMemcpyAsync(tmp, mrow, nm * Q * 8, hipMemcpyHostToDevice, e->stream);
             if (herr == hipSuccess) {
-                hipLaunchKernelGGL(k_msgs_to_records, dim3(uint32_t((nm * (Q - 1) + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, e->stream, tmp, nm,
+                hipLaunchKernelGGL(k_msgs_to_records, dim3(uint32_t((nm + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, e->stream, tmp, nm,
                                    int(Q), e->d_M[e->cur] + k0 * (Q - 1));
                 herr = hipGetLastError();
             }
@@ -1066,7 +1067,7 @@ static int upload_messages(sbmbp_engine *e, const double *msg_out, double *dst) 
         const uint64_t n = std::min(slab, e->E2 - k0);
         hipError_t err = hipMemcpyAsync(tmp, msg_out + k0 * e->Q, n * e->Q * 8, hipMemcpyHostToDevice, e->stream);
         if (err == hipSuccess) {
-            hipLaunchKernelGGL(k_msgs_to_records, dim3(uint32_t((n * (e->Q - 1) + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, e->stream, tmp, n,
+            hipLaunchKernelGGL(k_msgs_to_records, dim3(uint32_t((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, e->stream, tmp, n,
                                int(e->Q), dst + k0 * (e->Q - 1));
             err = hipGetLastError();
         }

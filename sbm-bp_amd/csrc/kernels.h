@@ -122,49 +122,90 @@ template <int Q> __device__ __forceinline__ void store_vec_stream(double *__rest
 }
 // ---- message records ------------------------------------------------------------------------------
 // A message is a distribution over Q groups, so only MC = Q-1 components are kept in HBM (record k at
-// M + k*MC); the last one is restored on load as max(0, 1 - sum) (a NaN stays a NaN). This removes 8 bytes
-// from every message read and write of the sweep. The marginal table keeps all Q components: its rows are
-// GATHERED, and a 32-byte row aligned to 32 bytes costs one fabric request where a 24-byte row would
-// straddle two in a quarter of the cases.
-template <int Q> struct msg_rec { static constexpr int MC = Q - 1; };
-template <int Q> __device__ __forceinline__ void finish_msg(double (&v)[Q]) {
-    double s = v[0];
+// M + k*MC): 8 bytes less on every message read and write of the sweep. The component left out is the
+// LARGEST one, restored on load as max(0, 1 - sum of the others) (a NaN stays a NaN): the small components keep
+// their full relative precision - with a forbidden group pair (a zero in cab) a component of 1e-20 still decides
+// between groups, and leaving out a fixed component would round it to an exact zero as soon as the others reach
+// 1 - 1e-16. Which component was left out is written into the (otherwise unused) sign bits of the first NB stored
+// components. The marginal table keeps all Q components: its rows are GATHERED, and a 32-byte row aligned to 32
+// bytes costs one fabric request where a 24-byte row would straddle two in a quarter of the cases.
+template <int Q> struct msg_rec {
+    static constexpr int MC = Q - 1;
+    static constexpr int NB = (Q <= 2) ? 1 : (Q <= 4) ? 2 : (Q <= 8) ? 3 : 4;  // bits of the left-out index (NB <= MC)
+};
+__device__ __forceinline__ unsigned sign_bit(double x) { return unsigned(static_cast<unsigned long long>(__double_as_longlong(x)) >> 63); }
+__device__ __forceinline__ double with_sign(double x, unsigned bit) {
+    const unsigned long long u = static_cast<unsigned long long>(__double_as_longlong(x)) & 0x7fffffffffffffffull;
+    return __longlong_as_double(static_cast<long long>(u | (static_cast<unsigned long long>(bit & 1u) << 63)));
+}
+// w[0..MC): the stored words -> v[0..Q)
+template <int Q> __device__ __forceinline__ void decode_msg(const double (&w)[Q > 1 ? Q - 1 : 1], double (&v)[Q]) {
+    constexpr int MC = msg_rec<Q>::MC, NB = msg_rec<Q>::NB;
+    unsigned idx = 0;
 #pragma unroll
-    for (int q = 1; q < Q - 1; ++q) s += v[q];
-    const double r = 1.0 - s;
-    v[Q - 1] = r < 0.0 ? 0.0 : r;
+    for (int j = 0; j < NB; ++j) idx |= sign_bit(w[j]) << j;
+    idx = idx < unsigned(Q) ? idx : unsigned(Q - 1);  // garbage (NaN records) stays in range
+    double a[MC];
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < MC; ++j) { a[j] = fabs(w[j]); s += a[j]; }
+    double big = 1.0 - s;
+    big = big < 0.0 ? 0.0 : big;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        const double lo = a[k < MC ? k : MC - 1];      // used when k < idx
+        const double hi = a[k > 0 ? k - 1 : 0];        // used when k > idx
+        v[k] = unsigned(k) < idx ? lo : (unsigned(k) == idx ? big : hi);
+    }
+}
+template <int Q> __device__ __forceinline__ void encode_msg(const double (&v)[Q], double (&w)[Q > 1 ? Q - 1 : 1]) {
+    constexpr int MC = msg_rec<Q>::MC, NB = msg_rec<Q>::NB;
+    unsigned idx = 0;
+    double vmax = v[0];
+#pragma unroll
+    for (int k = 1; k < Q; ++k) if (v[k] > vmax) { vmax = v[k]; idx = unsigned(k); }  // first maximum; NaNs compare false
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+        double o = unsigned(j) < idx ? v[j] : v[j + 1];
+        if (j < NB) o = with_sign(o, idx >> j);
+        w[j] = o;
+    }
 }
 template <int Q> __device__ __forceinline__ void load_msg(const double *__restrict__ M, size_t k, double (&v)[Q]) {
     constexpr int MC = msg_rec<Q>::MC;
     const double *p = M + k * MC;
+    double w[MC];
     if (MC % 2 == 0) {
         const double2 *p2 = reinterpret_cast<const double2 *>(p);
 #pragma unroll
-        for (int j = 0; j < MC / 2; ++j) { double2 t = p2[j]; v[2 * j] = t.x; v[2 * j + 1] = t.y; }
+        for (int j = 0; j < MC / 2; ++j) { double2 t = p2[j]; w[2 * j] = t.x; w[2 * j + 1] = t.y; }
     } else {
 #pragma unroll
-        for (int q = 0; q < MC; ++q) v[q] = p[q];
+        for (int q = 0; q < MC; ++q) w[q] = p[q];
     }
-    finish_msg<Q>(v);
+    decode_msg<Q>(w, v);
 }
 template <int Q> __device__ __forceinline__ void store_msg(double *__restrict__ M, size_t k, const double (&v)[Q]) {
     constexpr int MC = msg_rec<Q>::MC;
     double *p = M + k * MC;
+    double w[MC];
+    encode_msg<Q>(v, w);
     if (MC % 2 == 0) {
         double2 *p2 = reinterpret_cast<double2 *>(p);
 #pragma unroll
-        for (int j = 0; j < MC / 2; ++j) p2[j] = make_double2(v[2 * j], v[2 * j + 1]);
+        for (int j = 0; j < MC / 2; ++j) p2[j] = make_double2(w[2 * j], w[2 * j + 1]);
     } else {
 #pragma unroll
-        for (int q = 0; q < MC; ++q) p[q] = v[q];
+        for (int q = 0; q < MC; ++q) p[q] = w[q];
     }
 }
 template <int Q> __device__ __forceinline__ void load_msg_stream(const double *__restrict__ M, size_t k, double (&v)[Q]) {
 #if SBMBP_NT & 1
     constexpr int MC = msg_rec<Q>::MC;
+    double w[MC];
 #pragma unroll
-    for (int q = 0; q < MC; ++q) v[q] = __builtin_nontemporal_load(M + k * MC + q);
-    finish_msg<Q>(v);
+    for (int q = 0; q < MC; ++q) w[q] = __builtin_nontemporal_load(M + k * MC + q);
+    decode_msg<Q>(w, v);
 #else
     load_msg<Q>(M, k, v);
 #endif
@@ -172,11 +213,44 @@ template <int Q> __device__ __forceinline__ void load_msg_stream(const double *_
 template <int Q> __device__ __forceinline__ void store_msg_stream(double *__restrict__ M, size_t k, const double (&v)[Q]) {
 #if SBMBP_NT & 2
     constexpr int MC = msg_rec<Q>::MC;
+    double w[MC];
+    encode_msg<Q>(v, w);
 #pragma unroll
-    for (int q = 0; q < MC; ++q) __builtin_nontemporal_store(v[q], M + k * MC + q);
+    for (int q = 0; q < MC; ++q) __builtin_nontemporal_store(w[q], M + k * MC + q);
 #else
     store_msg<Q>(M, k, v);
 #endif
+}
+// marginal rows shipped between shards leave out their LAST component (plain first Q-1; k_pack_rows / k_unpack_rows)
+template <int Q> __device__ __forceinline__ void finish_last(double (&v)[Q]) {
+    double s = v[0];
+#pragma unroll
+    for (int q = 1; q < Q - 1; ++q) s += v[q];
+    const double r = 1.0 - s;
+    v[Q - 1] = r < 0.0 ? 0.0 : r;
+}
+// the same encoding with a run-time Q (state conversion, initialisation, the exact-criterion kernel)
+__device__ __forceinline__ void decode_msg_rt(const double *w, int Q, double *v) {
+    const int mc = Q - 1, nb = (Q <= 2) ? 1 : (Q <= 4) ? 2 : (Q <= 8) ? 3 : 4;
+    unsigned idx = 0;
+    for (int j = 0; j < nb; ++j) idx |= sign_bit(w[j]) << j;
+    idx = idx < unsigned(Q) ? idx : unsigned(Q - 1);
+    double s = 0.0;
+    for (int j = 0; j < mc; ++j) s += fabs(w[j]);
+    double big = 1.0 - s;
+    big = big < 0.0 ? 0.0 : big;
+    for (int k = 0; k < Q; ++k) v[k] = unsigned(k) < idx ? fabs(w[k]) : (unsigned(k) == idx ? big : fabs(w[k - 1]));
+}
+__device__ __forceinline__ void encode_msg_rt(const double *v, int Q, double *w) {
+    const int mc = Q - 1, nb = (Q <= 2) ? 1 : (Q <= 4) ? 2 : (Q <= 8) ? 3 : 4;
+    unsigned idx = 0;
+    double vmax = v[0];
+    for (int k = 1; k < Q; ++k) if (v[k] > vmax) { vmax = v[k]; idx = unsigned(k); }
+    for (int j = 0; j < mc; ++j) {
+        double o = unsigned(j) < idx ? v[j] : v[j + 1];
+        if (j < nb) o = with_sign(o, idx >> j);
+        w[j] = o;
+    }
 }
 __device__ __forceinline__ uint32_t load_idx_stream(const uint32_t *__restrict__ p) {
 #if SBMBP_NT & 1
@@ -615,7 +689,12 @@ struct shard_io {
 };
 template <int Q> __device__ __forceinline__ void load_halo_row(const shard_io &io, uint32_t h, double (&v)[Q]) {
     if (io.ncomp == Q) load_vec<Q>(io.halo_stage + size_t(h) * Q, v);
-    else load_msg<Q>(io.halo_stage, h, v);  // Q-1 components; the last is max(0, 1 - sum), as k_unpack_rows restores it
+    else {  // first Q-1 components; the last is max(0, 1 - sum), as k_unpack_rows restores it
+        const double *p = io.halo_stage + size_t(h) * (Q - 1);
+#pragma unroll
+        for (int q = 0; q < Q - 1; ++q) v[q] = p[q];
+        finish_last<Q>(v);
+    }
 }
 template <int Q> __device__ __forceinline__ void send_row(const shard_io &io, uint32_t i, const double (&pv)[Q]) {
     for (uint32_t s = io.snd_ptr[i]; s < io.snd_ptr[i + 1]; ++s) {
@@ -702,7 +781,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
 #pragma unroll
             for (int q = 0; q < Q - 1; ++q) pl[j][q] = src[q];
             const double lastv = src[full ? Q - 1 : 0];
-            finish_msg<Q>(pl[j]);
+            finish_last<Q>(pl[j]);
             if (full) pl[j][Q - 1] = lastv;
         } else {
             load_vec<Q>(psi_old + size_t(nl[j]) * Q, pl[j]);
@@ -974,24 +1053,18 @@ k_unpack_rows(const double *__restrict__ in, uint32_t n, int Q, int ncomp, doubl
     if (ncomp < Q) table[row * Q + (Q - 1)] = fmax(0.0, 1.0 - s);
 }
 
-// exact 1-step criterion of converge (bp.cpp:1059-1063): max over all message entries |a - b|, the implied
-// last component of every record included
+// exact 1-step criterion of converge (bp.cpp:1059-1063): max over all message entries |a - b| (records decoded)
 __global__ void __launch_bounds__(BLOCK)
 k_msg_diff(const double *__restrict__ a, const double *__restrict__ b, uint64_t n_msg, int mc, double *__restrict__ partials) {
     __shared__ double sred[4 * 2];
     double md = 0.0;
+    const int Q = mc + 1;
     for (uint64_t k = uint64_t(blockIdx.x) * BLOCK + threadIdx.x; k < n_msg; k += uint64_t(gridDim.x) * BLOCK) {
-        double sa = 0.0, sb = 0.0;
-        for (int q = 0; q < mc; ++q) {
-            const double x = a[k * mc + q], y = b[k * mc + q];
-            md = nanmax(md, fabs(x - y));
-            sa += x;
-            sb += y;
-        }
-        double ra = 1.0 - sa, rb = 1.0 - sb;
-        ra = ra < 0.0 ? 0.0 : ra;
-        rb = rb < 0.0 ? 0.0 : rb;
-        md = nanmax(md, fabs(ra - rb));
+        double wa[QMAX], wb[QMAX], va[QMAX], vb[QMAX];
+        for (int q = 0; q < mc; ++q) { wa[q] = a[k * mc + q]; wb[q] = b[k * mc + q]; }
+        decode_msg_rt(wa, Q, va);
+        decode_msg_rt(wb, Q, vb);
+        for (int q = 0; q < Q; ++q) md = nanmax(md, fabs(va[q] - vb[q]));
     }
     double dummy[1] = {0.0};
     block_reduce_store<1, 4>(dummy, md, sred, partials + size_t(blockIdx.x) * 2);
@@ -1707,33 +1780,40 @@ __device__ __forceinline__ double u01(uint64_t seed, uint64_t idx) {
     z ^= z >> 31;
     return (double(z >> 11) + 0.5) * (1.0 / 9007199254740992.0);
 }
-// ncomp = Q for marginal rows, Q-1 for message records (the last component is implied)
+// ncomp = Q: marginal rows; ncomp = Q-1: message records (encoded, see msg_rec)
 __global__ void __launch_bounds__(BLOCK)
 k_init_random(double *__restrict__ v, uint64_t n_vec, int Q, int ncomp, uint64_t seed, uint64_t salt, uint64_t index0) {
     const uint64_t i = uint64_t(blockIdx.x) * BLOCK + threadIdx.x;
     if (i >= n_vec) return;
-    double t[QMAX], norm = 0.0;
+    double t[QMAX], w[QMAX], norm = 0.0;
     for (int q = 0; q < Q; ++q) { t[q] = u01(seed ^ salt, (index0 + i) * uint64_t(Q) + q); norm += t[q]; }
-    for (int q = 0; q < ncomp; ++q) v[i * ncomp + q] = t[q] / norm;
+    for (int q = 0; q < Q; ++q) t[q] /= norm;
+    if (ncomp == Q) {
+        for (int q = 0; q < Q; ++q) v[i * Q + q] = t[q];
+    } else {
+        encode_msg_rt(t, Q, w);
+        for (int q = 0; q < ncomp; ++q) v[i * ncomp + q] = w[q];
+    }
 }
 
-// host layout (Q components per message, sbmbp_set_state / sbmbp_get_state) <-> message records (Q-1 components)
+// host layout (Q components per message, sbmbp_set_state / sbmbp_get_state) <-> message records (Q-1 words)
 __global__ void __launch_bounds__(BLOCK)
 k_msgs_to_records(const double *__restrict__ full, uint64_t n_msg, int Q, double *__restrict__ rec) {
-    const uint64_t t = uint64_t(blockIdx.x) * BLOCK + threadIdx.x;
-    const int mc = Q - 1;
-    if (t >= n_msg * mc) return;
-    rec[t] = full[(t / mc) * Q + (t % mc)];
+    const uint64_t k = uint64_t(blockIdx.x) * BLOCK + threadIdx.x;
+    if (k >= n_msg) return;
+    double v[QMAX], w[QMAX];
+    for (int q = 0; q < Q; ++q) v[q] = full[k * Q + q];
+    encode_msg_rt(v, Q, w);
+    for (int q = 0; q < Q - 1; ++q) rec[k * (Q - 1) + q] = w[q];
 }
 __global__ void __launch_bounds__(BLOCK)
 k_records_to_msgs(const double *__restrict__ rec, uint64_t n_msg, int Q, double *__restrict__ full) {
     const uint64_t k = uint64_t(blockIdx.x) * BLOCK + threadIdx.x;
     if (k >= n_msg) return;
-    const int mc = Q - 1;
-    double s = 0.0;
-    for (int q = 0; q < mc; ++q) { const double v = rec[k * mc + q]; full[k * Q + q] = v; s += v; }
-    const double r = 1.0 - s;
-    full[k * Q + mc] = r < 0.0 ? 0.0 : r;
+    double v[QMAX], w[QMAX];
+    for (int q = 0; q < Q - 1; ++q) w[q] = rec[k * (Q - 1) + q];
+    decode_msg_rt(w, Q, v);
+    for (int q = 0; q < Q; ++q) full[k * Q + q] = v[q];
 }
 
 }  // namespace sbmbp
