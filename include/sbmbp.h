@@ -17,10 +17,11 @@
  * types.h:14-15); rev[k] = index of the reverse directed edge; messages are OUT-ordered AoS:
  * msg[k*Q+q] = message from row(k) to nbr[k]. The reference's in-ordered mmap_[i][l][q]
  * (belief_propagation.h:65-66) is msg[rev[row_ptr[i]+l]*Q+q]. That is the layout AT THIS BOUNDARY
- * (sbmbp_set_state / sbmbp_get_state / sbmbp_host_init_state). On the device a message is kept as its
- * first Q-1 components (messages are distributions: every row of msg must sum to 1, as every message
- * the reference produces does) and the last is restored as max(0, 1 - sum); sbmbp_get_state therefore
- * returns that component within a few ulp of what sbmbp_set_state was given, the others bit for bit.
+ * (sbmbp_set_state / sbmbp_get_state / sbmbp_host_init_state). On the device a message is kept as Q-1 of
+ * its components (messages are distributions: every row of msg must sum to 1, as every message the
+ * reference produces does): all but the largest, which is restored as max(0, 1 - sum of the others);
+ * sbmbp_get_state therefore returns that ONE component per message within a few ulp of what
+ * sbmbp_set_state was given, the others bit for bit.
  */
 #ifndef SBMBP_H
 #define SBMBP_H
