@@ -179,3 +179,42 @@ def test_random_instance_sharded_against_one_shard(S, seed):
     assert _close(fk, f1, 1e-10) and _close(ek, e1, 1e-9) and abs(o1 - ok) < 1e-12
     for a, b in zip(emk, em1):
         assert _close(a, b, 1e-9)
+
+
+@pytest.mark.parametrize("seed", _seeds("SBMBP_FUZZ_LEARN_SEEDS", (500, 24)))
+def test_random_instance_learning_against_the_oracle(S, orc, seed):
+    """-m learn on random planted instances (Q = 2..6, dc 0, random start parameters): the engine follows the oracle's
+    SYNCHRONOUS EM run step for step (same number of EM steps, same learned parameters)"""
+    from sbm_bp_amd import synth
+    rng = np.random.default_rng(7000 + seed)
+    Q = int(rng.choice([2, 3, 4, 6]))
+    N = int(rng.choice([120, 300, 600])) // Q * Q
+    c = float(rng.choice([4.0, 7.0, 10.0]))
+    eps = float(rng.choice([0.05, 0.15, 0.3]))
+    pairs, cin, cout = synth.planted_partition(N, Q, c, eps, 100 + seed)
+    tc = synth.true_conf(N, Q)
+    cab0 = synth.cab_matrix(Q, cin * rng.uniform(0.7, 1.3), cout * rng.uniform(0.7, 1.6))
+    na = np.array(synth.group_sizes(N, Q), dtype=np.uint32)
+    lr, lcrit, tmax = float(rng.choice([0.2, 0.5])), 1e-6, 60
+    g = S.Graph.from_edges(pairs, N)
+    og = orc.Graph.from_edges(pairs, N)
+    bm = S.blockmodel_t(g, Q, 0)
+    bp = S.bp_basic()
+    bp.init_messages(bm, 0, None, tc, seed)
+    st = S.bp_blockmodel_state(cab0, na)
+    res = bp.learning(bm, st, lcrit, tmax, lr, 1.0)
+    ob = orc.OracleBP(og, Q, 0)
+    ob.init_messages(0, None, tc, orc.Rng(seed))
+    ob.set_params(cab0, na, 1.0)
+    steps, f = ob.learning(lcrit, tmax, lr, 1.0, None, sync=True, series_K=0)
+    cab, na1 = bp.get_params()
+    ocab, ona = ob.get_params()
+    if not np.isfinite(f):
+        assert not np.isfinite(res.free_energy)
+        return
+    assert abs(res.em_steps - steps) <= 1, (res.em_steps, steps)
+    if res.em_steps == steps and steps < tmax:  # a run that hits the step limit is still moving: nothing to pin there
+        # group sizes are truncated to integers every EM step (bp.cpp:60-66): a last-bit difference can move one vertex
+        assert np.abs(na1.astype(np.int64) - ona.astype(np.int64)).max() <= 1
+        if list(na1) == list(ona):
+            assert np.abs(cab - ocab).max() < 1e-5 * np.abs(ocab).max() and abs(res.free_energy - f) < 1e-7 * max(1.0, abs(f))
