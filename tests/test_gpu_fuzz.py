@@ -218,3 +218,32 @@ def test_random_instance_learning_against_the_oracle(S, orc, seed):
         assert np.abs(na1.astype(np.int64) - ona.astype(np.int64)).max() <= 1
         if list(na1) == list(ona):
             assert np.abs(cab - ocab).max() < 1e-5 * np.abs(ocab).max() and abs(res.free_energy - f) < 1e-7 * max(1.0, abs(f))
+
+
+@pytest.mark.parametrize("seed", _seeds("SBMBP_FUZZ_SHARD_LEARN_SEEDS", (800, 10)))
+def test_random_instance_sharded_learning_against_one_shard(S, seed):
+    """-m learn over 2-4 shards (chunked exchange, fused send/receive buffers) follows the single shard's EM run"""
+    from sbm_bp_amd import synth
+    from sbm_bp_amd.distributed import LocalComm, ShardedBP
+    rng = np.random.default_rng(9000 + seed)
+    Q = int(rng.choice([2, 3, 4]))
+    N = int(rng.choice([300, 600, 1200])) // Q * Q
+    c = float(rng.choice([5.0, 8.0]))
+    pairs, cin, cout = synth.planted_partition(N, Q, c, float(rng.choice([0.05, 0.2])), 300 + seed)
+    tc = synth.true_conf(N, Q)
+    cab0 = synth.cab_matrix(Q, cin * rng.uniform(0.8, 1.2), cout * rng.uniform(0.8, 1.5))
+    na = np.array(synth.group_sizes(N, Q), dtype=np.uint32)
+    g = S.Graph.from_edges(pairs, N)
+    row_ptr, nbr, _ = g.csr()
+    out = []
+    for w in (1, int(rng.integers(2, 5))):
+        sb = ShardedBP.from_csr(row_ptr, nbr, Q, 0, LocalComm(w), n_chunks=int(rng.integers(1, 5)) if w > 1 else 1)
+        sb.init_messages_device(seed, tc)
+        sb.expand_bp_params(cab0, na, 1.0)
+        out.append(sb.learning(1e-6, 40, 0.3))
+    a, b = out
+    assert a["status"] == b["status"] and abs(a["em_steps"] - b["em_steps"]) <= 1
+    if a["em_steps"] == b["em_steps"] and a["status"] == 1 and list(a["na"]) == list(b["na"]):
+        assert np.abs(a["cab"] - b["cab"]).max() < 1e-7 * np.abs(a["cab"]).max()
+        assert abs(a["free_energy"] - b["free_energy"]) < 1e-9 * max(1.0, abs(a["free_energy"]))
+        assert abs(a["overlap"] - b["overlap"]) < 1e-9
