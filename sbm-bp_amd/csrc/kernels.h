@@ -1470,10 +1470,15 @@ __global__ void __launch_bounds__(BLOCK)
 k_moments(const double *__restrict__ psi, uint32_t n_rows, int Q, int K, uint32_t rows_per_blk, int T,
           double *__restrict__ partials /* [gridDim.x][T] */) {
     __shared__ double sp[BLOCK * QMAX];
+    __shared__ double scomb[BLOCK];
     const int tid = threadIdx.x;
-    constexpr int MAXE = 20;  // entries per thread: T <= 256*20 = 5120 >= 8+64+512+4096
+    constexpr int MAXE = 20;  // entries per thread: T <= 256*20 = 5120 >= 8+64+512+4096 (engine.hip: max_series_order)
     double acc[MAXE];
     for (int j = 0; j < MAXE; ++j) acc[j] = 0.0;
+    // few entries (T < 128, e.g. 84 for Q = 4 at order 3): several threads share one entry, each taking every nsub-th row
+    const int nsub = T < BLOCK / 2 ? BLOCK / T : 1;
+    const int sub = nsub > 1 ? tid / T : 0;
+    const bool active = nsub == 1 || tid < nsub * T;
     const uint32_t lo = blockIdx.x * rows_per_blk, hi = min(n_rows, lo + rows_per_blk);
     for (uint32_t base = lo; base < hi; base += BLOCK) {
         const uint32_t cnt = min(uint32_t(BLOCK), hi - base);
@@ -1481,7 +1486,7 @@ k_moments(const double *__restrict__ psi, uint32_t n_rows, int Q, int K, uint32_
         for (uint32_t x = tid; x < cnt * Q; x += BLOCK) sp[x] = psi[size_t(base) * Q + x];
         __syncthreads();
         int j = 0;
-        for (int ent = tid; ent < T; ent += BLOCK, ++j) {
+        for (int ent = nsub > 1 ? tid % T : tid; active && ent < T; ent += BLOCK, ++j) {
             // decode (order k, multi-index) of the packed entry
             int k = 1, off = 0, sz = Q;
             while (ent >= off + sz) { off += sz; sz *= Q; ++k; }
@@ -1489,7 +1494,7 @@ k_moments(const double *__restrict__ psi, uint32_t n_rows, int Q, int K, uint32_
             int a[4];
             for (int t = 0; t < 4; ++t) { a[t] = idx % Q; idx /= Q; }
             double s = 0.0;
-            for (uint32_t r = 0; r < cnt; ++r) {
+            for (uint32_t r = uint32_t(sub); r < cnt; r += uint32_t(nsub)) {
                 const double *p = &sp[r * Q];
                 double v = p[a[0]];
                 if (k > 1) v *= p[a[1]];
@@ -1499,6 +1504,17 @@ k_moments(const double *__restrict__ psi, uint32_t n_rows, int Q, int K, uint32_
             }
             acc[j] += s;
         }
+    }
+    if (nsub > 1) {  // combine the sub-sums of an entry in a fixed order
+        __syncthreads();
+        scomb[tid] = active ? acc[0] : 0.0;
+        __syncthreads();
+        if (tid < T) {
+            double s = scomb[tid];
+            for (int u = 1; u < nsub; ++u) s += scomb[u * T + tid];
+            partials[size_t(blockIdx.x) * T + tid] = s;
+        }
+        return;
     }
     int j = 0;
     for (int ent = tid; ent < T; ent += BLOCK, ++j) partials[size_t(blockIdx.x) * T + ent] = acc[j];
