@@ -82,6 +82,8 @@ struct sbmbp_engine {
     double beta = 1.0;
     double sum_log_didl = 0.0;  // sum over directed edges of log(d_i d_l) (dc 1 constant of f_site/f_edge)
     bool have_params = false, have_state = false, has_clamp = false, field_fresh = false;
+    void *h_cs = nullptr;            // page-locked: two convergence-state slots for the pipelined batch loop
+    hipEvent_t ev_cs[2] = {nullptr, nullptr};
     bool exact_mode = false;   // marginal-gather sweeps report the exact 1-step difference (they read the other message buffer too)
     bool clamp_onehot = false;  // the clamped rows hold the one-hot state of init flag 1/3: the marginal-gather sweep stays exact
     bool w_positive = false;     // every cab entry > 0: the marginal-gather sweep is well defined
@@ -351,18 +353,43 @@ int run_sweeps(sbmbp_engine *e, double crit, uint32_t max_sweeps, double damping
     uint64_t n_psi = 0;
     int result_iter = -1;
     double exact = -1.0;
-    while (done < max_sweeps) {
+    // Batches are queued one ahead: while the host waits for the convergence state of batch k, batch k+1 is already in
+    // the stream, so the GPU never idles at a batch boundary (after a stop the extra batch is a few no-op launches).
+    if (!e->h_cs) {
+        HIPCHK(hipHostMalloc(&e->h_cs, 2 * sizeof(conv_state), hipHostMallocDefault));
+        for (auto &ev : e->ev_cs) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    conv_state *slots = static_cast<conv_state *>(e->h_cs);
+    auto queue_batch = [&](int slot) -> int {
         const uint32_t batch = std::min(batch_max, max_sweeps - done);
         for (uint32_t b = 0; b < batch; ++b) {
             const uint32_t j = done + b;
             const bool pf = psi_ok && !(j == 0 && first_explicit);
             CHK(launch_sweep(e, j, damping, pf));
         }
-        CHK(read_conv_state(e, &cs));
-        if (e->timing) CHK(collect_timing(e));
         done += batch;
-        if (cs.stop) break;
+        HIPCHK(hipMemcpyAsync(&slots[slot], reinterpret_cast<const char *>(e->d_P) + offsetof(dev_params, maxdiff), sizeof(conv_state),
+                              hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipEventRecord(e->ev_cs[slot], e->stream));
+        return SBMBP_OK;
+    };
+    if (max_sweeps > 0) {
+        CHK(queue_batch(0));
+        for (int k = 0;; ++k) {
+            const bool more = done < max_sweeps;
+            if (more) CHK(queue_batch((k + 1) & 1));
+            HIPCHK(hipEventSynchronize(e->ev_cs[k & 1]));
+            cs = slots[k & 1];
+            if (cs.stop || !more) {
+                if (more) {  // drain the batch queued ahead (no-ops after a stop)
+                    HIPCHK(hipEventSynchronize(e->ev_cs[(k + 1) & 1]));
+                    cs = slots[(k + 1) & 1];
+                }
+                break;
+            }
+        }
     }
+    if (e->timing) CHK(collect_timing(e));
     uint32_t executed = uint32_t(cs.sweep_idx);
     auto commit = [&](uint32_t n) {
         e->cur = (e->cur + int(n)) & 1;
@@ -918,6 +945,8 @@ void sbmbp_destroy(sbmbp_engine_t *e) {
                     e->d_stage};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto ev : e->ev) hipEventDestroy(ev);
+    if (e->h_cs) (void)hipHostFree(e->h_cs);
+    for (auto ev : e->ev_cs) if (ev) hipEventDestroy(ev);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
     if (e->hub_stream) hipStreamDestroy(e->hub_stream);
