@@ -56,10 +56,15 @@ struct dev_params {
 #ifndef SBMBP_PSI_WAVES
 #define SBMBP_PSI_WAVES 0  // > 0: min waves per SIMD requested for k_sweep_psi (register cap)
 #endif
+#ifndef SBMBP_XCD_REMAP
+#define SBMBP_XCD_REMAP 1  // contiguous eighth of the segments per XCD (A/B on MI355X: C3 2.551 -> 2.504 ms, C5 0.1258 -> 0.1226 ms)
+#endif
 #ifndef SBMBP_FRAME_TPB
 #define SBMBP_FRAME_TPB 256  // threads per workgroup of the frame kernels (multiple of 64)
 #endif
 constexpr int FTPB = SBMBP_FRAME_TPB;
+// launch grid of the marginal-gather sweep for n segments (padded for the XCD mapping)
+inline uint32_t xcd_grid(uint32_t n) { return SBMBP_XCD_REMAP ? 8u * ((n + 7u) / 8u) : n; }
 constexpr int FWAVES = FTPB / 64;
 
 template <int Q> struct frame_cfg {
@@ -717,7 +722,7 @@ __launch_bounds__(FTPB)
 k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, double *__restrict__ Mio,
             const double *__restrict__ psi_old, double *__restrict__ psi_new, const uint32_t *__restrict__ blk_row,
             const uint32_t *__restrict__ blk_e0, const dev_params *__restrict__ P, int dc, double *__restrict__ partials,
-            const int32_t *__restrict__ clamp, shard_io io,
+            const int32_t *__restrict__ clamp, shard_io io, uint32_t n_seg /* segments = workgroups with work */,
             const double *__restrict__ Mcmp /* null: report the 2-step difference against the own previous message;
                                                else the other message buffer (m^t): report the exact 1-step difference */) {
     constexpr int EPT = frame_cfg<Q>::EPT, CAP = frame_cfg<Q>::CAP, RCAP = frame_cfg<Q>::RCAP;
@@ -738,9 +743,19 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     // overlaps them.
     const int tid = threadIdx.x;
     const int stop = P->stop;
-    const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
-    const uint32_t e0 = blk_e0[blockIdx.x];
-    const int nrows = int(r1 - r0), ne = int(blk_e0[blockIdx.x + 1] - e0);
+#if SBMBP_XCD_REMAP
+    // Workgroup i is dispatched to XCD i % 8. The grid is padded to 8 * per workgroups (xcd_grid) and XCD x takes the
+    // contiguous segments [x * per, (x+1) * per): its L2 then sees one stretch of rows, messages and marginals instead of
+    // every eighth segment of the whole graph.
+    const uint32_t per = gridDim.x / 8;
+    const uint32_t bid = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (bid >= n_seg) return;  // padding (uniform per workgroup)
+#else
+    const uint32_t bid = blockIdx.x;
+#endif
+    const uint32_t r0 = blk_row[bid], r1 = blk_row[bid + 1];
+    const uint32_t e0 = blk_e0[bid];
+    const int nrows = int(r1 - r0), ne = int(blk_e0[bid + 1] - e0);
     if (stop || ne > CAP) return;  // stopped run, or hub row (k_sweep_psi_hub owns it): uniform exit before any barrier
 
     // ---- phase 1: lane per directed edge. Loads are branch-free (inactive lanes re-read the segment's first
@@ -938,7 +953,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
             store_msg_stream<Q>(Mio, size_t(e0 + le), out);
         }
     }
-    block_reduce_store<Q, FWAVES>(Sacc, md, sred, partials + size_t(blockIdx.x) * (Q + 1));
+    block_reduce_store<Q, FWAVES>(Sacc, md, sred, partials + size_t(bid) * (Q + 1));
 }
 
 // K1ph: marginal-gather form of the hub-row update (one workgroup per row with degree > CAP)
