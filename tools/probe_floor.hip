@@ -38,8 +38,15 @@ __global__ void __launch_bounds__(256) probe3(const uint32_t* __restrict__ nbr, 
                                               double2* __restrict__ psi_new, uint32_t n_edges, uint32_t n_rows,
                                               const uint32_t* __restrict__ blk_e0 = nullptr) {
     double* __restrict__ M = reinterpret_cast<double*>(M2);
-    const uint32_t base = blk_e0[blockIdx.x] + threadIdx.x;
-    n_edges = min(n_edges, blk_e0[blockIdx.x + 1]);
+#ifdef PROBE_XCD  // every XCD (workgroup i runs on XCD i % 8) takes a contiguous eighth of the segments, as k_sweep_psi does
+    const uint32_t per = (gridDim.x + 7) / 8;
+    const uint32_t bid = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (bid >= gridDim.x) return;
+#else
+    const uint32_t bid = blockIdx.x;
+#endif
+    const uint32_t base = blk_e0[bid] + threadIdx.x;
+    n_edges = min(n_edges, blk_e0[bid + 1]);
     uint32_t l[EPT]; double2 a[EPT][2]; double m[EPT][3];
 #pragma unroll
     for (int j = 0; j < EPT; ++j) { uint32_t k = base + j * 256; l[j] = k < n_edges ? nbr[k] : 0; }
