@@ -261,12 +261,13 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form) {
     if (psi_form) {
         if (clamp) {
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, true, false>), dim3(xcd_grid(e->n_blk)), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
-                                                Mnew, psi_old, psi_new, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), e->d_partials, clamp, shard_io{}, e->n_blk,
+                                                Mnew, psi_old, psi_new, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), e->d_partials, clamp, shard_io{}, e->n_blk, SBMBP_XCD_REMAP,
                                                 e->exact_mode ? Mold : nullptr));
         } else {
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, false>), dim3(xcd_grid(e->n_blk)), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
                                                 Mnew, psi_old, psi_new, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), e->d_partials,
-                                                (const int32_t *)nullptr, shard_io{}, e->n_blk, e->exact_mode ? Mold : nullptr));
+                                                (const int32_t *)nullptr, shard_io{}, e->n_blk, SBMBP_XCD_REMAP,
+                                                e->exact_mode ? Mold : nullptr));
         }
     } else if (e->dc == 2) {
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, true>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
@@ -1520,13 +1521,13 @@ int sbmbp_shard_sweep_chunk(sbmbp_engine_t *e, uint32_t j, uint32_t c) {
     if (nb)
     {
         if (io.snd_ptr) {
-            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, true>), dim3(xcd_grid(nb)), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr, Mio,
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, true>), dim3(nb), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr, Mio,
                                                 psi_old, psi_new, e->d_blk_row + b0, e->d_blk_e0 + b0, e->d_P, int(e->dc),
-                                                e->d_partials + size_t(b0) * (e->Q + 1), (const int32_t *)nullptr, io, nb, Mcmp));
+                                                e->d_partials + size_t(b0) * (e->Q + 1), (const int32_t *)nullptr, io, nb, 0, Mcmp));
         } else {
-            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, false>), dim3(xcd_grid(nb)), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr, Mio,
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, false>), dim3(nb), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr, Mio,
                                                 psi_old, psi_new, e->d_blk_row + b0, e->d_blk_e0 + b0, e->d_P, int(e->dc),
-                                                e->d_partials + size_t(b0) * (e->Q + 1), (const int32_t *)nullptr, io, nb, Mcmp));
+                                                e->d_partials + size_t(b0) * (e->Q + 1), (const int32_t *)nullptr, io, nb, 0, Mcmp));
         }
     }
     if (e->timing && nb) HIPCHK(hipEventRecord(e1, e->stream));
