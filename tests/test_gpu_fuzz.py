@@ -104,7 +104,8 @@ def test_random_instance_against_the_oracle(S, orc, seed):
             assert (np.isnan(psi) == np.isnan(opsi)).all() and (np.isnan(msg) == np.isnan(omsg)).all()
             ok = ~np.isnan(omsg)
             assert np.abs(msg[ok] - omsg[ok]).max(initial=0.0) < 1e-11
-            assert np.isnan(d1)
+            if np.isnan(omsg).any():  # (a NaN marginal alone - a row whose neighbours contradict each other - leaves the messages finite)
+                assert np.isnan(d1)
             continue
         assert np.abs(psi - opsi).max() < 1e-11 and (msg.size == 0 or np.abs(msg - omsg).max() < 1e-11), "sweep %d" % k
         assert abs(d1 - d2) < 1e-11
