@@ -19,14 +19,18 @@ N, Q, c, eps, dc, gseed = WORKLOADS[wl]
 torch.cuda.set_device(0)
 S.load_library()
 t0 = time.perf_counter()
-pairs, cin, cout = synth.planted_partition(N, Q, c, eps, gseed)
+if wl == "C4":
+    pairs, cab_c4, _ = synth.dc_sbm_powerlaw(N, Q, c, eps, gseed)
+else:
+    pairs, cin, cout = synth.planted_partition(N, Q, c, eps, gseed)
 g = S.Graph.from_edges(pairs, N)
 del pairs
 row_ptr, nbr, _ = g.csr()
 del g
 print("graph: N=%d E2=%d in %.1f s" % (N, len(nbr), time.perf_counter() - t0), flush=True)
 tc = synth.true_conf(N, Q)
-cab, na = synth.cab_matrix(Q, cin, cout), np.array(synth.group_sizes(N, Q), dtype=np.uint32)
+cab = cab_c4 if wl == "C4" else synth.cab_matrix(Q, cin, cout)
+na = np.array(synth.group_sizes(N, Q), dtype=np.uint32)
 
 
 def run(w):
