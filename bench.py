@@ -182,6 +182,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = runner.stats()
+    phases = runner.phase_times() if sharded else None
     kernel_ms = st.sweep_kernel_ms / max(1, st.sweep_launches)
     bytes_per_launch = st.bytes_per_sweep  # this rank's rows/edges: what ONE launch of k_sweep processes
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -212,6 +213,8 @@ def main():
             out["config"]["exchange"] = {"chunks": int(p0.n_chunks), "payload_components": int(sh0.ncomp),
                                          "halo_rows": int(p0.n_halo), "sent_MB_per_sweep": round(float(per_peer.sum()), 2),
                                          "busiest_peer_MB_per_sweep": round(float(per_peer.max()) if len(per_peer) else 0.0, 2)}
+            if phases:  # rank 0's stream: chunk kernels / fold + all-gather + finalize / wait for exchanges still in flight
+                out["config"]["exchange"]["rank0_ms_per_sweep"] = {k: round(v, 4) for k, v in phases.items() if k != "sweeps"}
         if rehearsal:
             out["rehearsal"] = "ranks share cuda:0, gloo collectives staged through the host: not a measurement"
         if sweeps_to_converge is not None:

@@ -332,6 +332,7 @@ class ShardedBP:
             backend_factory = lambda plan: HipShardBackend(plan, Q, dc, dev, compress=compress)  # noqa: E731
         self.shards = [backend_factory(p) for p in plans]
         self.fused = all(getattr(sh, "fused", False) for sh in self.shards)
+        self._timing, self._phase_log = False, []
         self.N_global = plans[0].n_global
         self.E2_local = sum(p.n_edges for p in plans)
         self.E2_global = None
@@ -444,10 +445,15 @@ class ShardedBP:
         the new marginals of chunk c travel while chunk c+1 is swept"""
         works = []
         fused = self.fused
+        ev = self._phase_events() if self._timing else None
+        if ev:
+            ev[0].record()
         for c in range(self.plans[0].n_chunks):
             for sh in self.shards:
                 sh.sweep_chunk(j, c)
             works += self._exchange_chunk(j + 1, c, packed=fused)
+        if ev:
+            ev[1].record()
         if not fused:
             for w in works:
                 w.wait()
@@ -459,8 +465,33 @@ class ShardedBP:
         self._gather_red()
         for sh in self.shards:
             sh.finalize(0, self.comm.world)
+        if ev:
+            ev[2].record()
         for w in works:  # the next sweep reads the receive buffers: its kernels wait for the exchanges here
             w.wait()
+        if ev:
+            ev[3].record()
+
+    # -- where a sweep's time goes on this rank's stream (bench diagnostics, only while timing is on) ------------------
+    def _phase_events(self):
+        import torch
+        quad = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        self._phase_log.append(quad)
+        return quad
+
+    def phase_times(self):
+        """mean ms per sweep on the compute stream: the chunk kernels (with whatever exchange time they could not hide
+        behind), fold + field all-gather + finalize, and the wait for the exchanges still in flight after that"""
+        import torch
+        if not self._phase_log:
+            return None
+        torch.cuda.synchronize()
+        n = len(self._phase_log)
+        out = {"chunks_ms": sum(q[0].elapsed_time(q[1]) for q in self._phase_log) / n,
+               "reduce_ms": sum(q[1].elapsed_time(q[2]) for q in self._phase_log) / n,
+               "exchange_wait_ms": sum(q[2].elapsed_time(q[3]) for q in self._phase_log) / n, "sweeps": n}
+        self._phase_log = []
+        return out
 
     def _begin(self, armed):
         works = []
@@ -667,5 +698,7 @@ class ShardedBP:
             sh.reset_stats()
 
     def set_timing(self, on):
+        self._timing = bool(on) and self.shards and hasattr(self.shards[0], "torch")  # HIP shards only
+        self._phase_log = []
         for sh in self.shards:
             sh.set_timing(on)
