@@ -299,6 +299,41 @@ def test_full_size_properties_c2(S):
     assert np.isfinite(f)
 
 
+def test_full_size_properties_c3(S):
+    """BASELINE's headline configuration C3 (N=1e7, Q=4, c=10: 1e8 directed edges) through size-independent properties:
+    bitwise reproducibility, the two sweep forms agreeing, field consistency, convergence in the documented number of
+    sweeps with the planted groups recovered. (State is compared through reductions: 3.5 GB of messages stay on the device.)"""
+    from sbm_bp_amd import synth
+    N, Q = 10_000_000, 4
+    pairs, cin, cout = synth.planted_partition(N, Q, 10.0, 0.1, 2)
+    g = S.Graph.from_edges(pairs, N)
+    del pairs
+    assert g.E2 > 99_000_000
+    tc = synth.true_conf(N, Q)
+    st = S.bp_blockmodel_state(synth.cab_matrix(Q, cin, cout), np.array([N // Q] * Q, dtype=np.uint32))
+    bm = S.blockmodel_t(g, Q, 0)
+    runs = []
+    for mode in (0, 0, 1):  # marginal gather twice, then message gather
+        bp = S.bp_conditional()
+        bp.init_messages_device(bm, tc, 1234)
+        bp.expand_bp_params(st)
+        bp.set_gather_mode(mode)
+        diffs = [bp.sweep(1, 1.0) for _ in range(4)]
+        runs.append((diffs, bp.compute_overlap(), bp.compute_free_energy(), bp.confusion(), bp.h().copy()))
+        assert bp.stats().psi_form_sweeps == (3 if mode == 0 else 0)
+        if mode == 1:
+            last = bp
+        else:
+            del bp
+    (d0, o0, f0, c0, h0), (d1, o1, f1, c1, h1), (d2, o2, f2, c2, h2) = runs
+    assert d0 == d1 and o0 == o1 and f0 == f1 and (c0 == c1).all() and (h0 == h1).all()  # run to run: bit for bit
+    assert np.abs(np.array(d0) - np.array(d2)).max() < 1e-12 and abs(o0 - o2) < 1e-12 and abs(f0 - f2) < 1e-10 * abs(f0)
+    assert np.abs(c0 - c2).max() < 1e-6 * N and abs(c0.sum() - N) < 1e-6 * N  # the marginals sum to one per vertex
+    niter, diff = last.converge(5e-6, 200, 1.0)
+    assert 25 <= niter + 4 + 1 <= 45 and diff < 5e-6  # 35 sweeps from this start (DESIGN.md)
+    assert last.compute_overlap() > 0.97
+
+
 def test_marginal_gather_and_message_gather_forms_agree(S):
     """the two forms of the sweep kernel produce the same iterates, niter and fixed point"""
     a = args_of(golden("q4_tight_seed0"))
