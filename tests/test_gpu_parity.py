@@ -334,6 +334,45 @@ def test_full_size_properties_c3(S):
     assert last.compute_overlap() > 0.97
 
 
+def test_full_size_properties_c4_c5(S):
+    """the other two BASELINE configurations at full size. C4 (power-law DC-SBM, Q=8, N=1e6, rows of up to ~2500 edges: segment,
+    wave-product and hub kernels in one sweep): reproducible, both sweep forms agree. C5 (N=1e6, Q=4, c=5): -m learn from
+    (0.9 cin, 1.8 cout) recovers the planted parameters."""
+    from sbm_bp_amd import synth
+    N, Q = 1_000_000, 8
+    pairs, cab, _ = synth.dc_sbm_powerlaw(N, Q, 8.0, 0.1, 3)
+    g = S.Graph.from_edges(pairs, N)
+    del pairs
+    tc = synth.true_conf(N, Q)
+    bm = S.blockmodel_t(g, Q, 1)
+    st = S.bp_blockmodel_state(cab, np.array([N // Q] * Q, dtype=np.uint32))
+    runs = []
+    for mode in (0, 0, 1):
+        bp = S.bp_conditional()
+        bp.init_messages_device(bm, tc, 99)
+        bp.expand_bp_params(st)
+        bp.set_gather_mode(mode)
+        assert bp.stats().n_hub_rows > 100
+        d = [bp.sweep(1, 1.0) for _ in range(4)]
+        runs.append((d, bp.compute_overlap(), bp.compute_free_energy(), bp.get_state()[0]))
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2] and (runs[0][3] == runs[1][3]).all()
+    assert np.abs(np.array(runs[0][0]) - np.array(runs[2][0])).max() < 1e-11 and np.abs(runs[0][3] - runs[2][3]).max() < 1e-11
+    assert abs(runs[0][2] - runs[2][2]) < 1e-10 * abs(runs[0][2]) and np.abs(runs[0][3].sum(1) - 1).max() < 1e-14
+    del runs, bp, g, bm
+    N, Q = 1_000_000, 4
+    pairs, cin, cout = synth.planted_partition(N, Q, 5.0, 0.1, 4)
+    g = S.Graph.from_edges(pairs, N)
+    del pairs
+    bm = S.blockmodel_t(g, Q, 0)
+    bp = S.bp_basic()
+    bp.init_messages_device(bm, synth.true_conf(N, Q), 7)
+    start = S.bp_blockmodel_state(synth.cab_matrix(Q, 0.9 * cin, 1.8 * cout), np.array([N // Q] * Q, dtype=np.uint32))
+    res = bp.learning(bm, start, 1e-6, 100, 0.2, 1.0)
+    learned, _ = bp.get_params()
+    assert res.status == 1 and res.em_steps < 60 and res.overlap > 0.85
+    assert abs(np.diag(learned).mean() - cin) < 0.01 * cin and abs((learned.sum() - np.trace(learned)) / (Q * Q - Q) - cout) < 0.02 * cout
+
+
 def test_marginal_gather_and_message_gather_forms_agree(S):
     """the two forms of the sweep kernel produce the same iterates, niter and fixed point"""
     a = args_of(golden("q4_tight_seed0"))
