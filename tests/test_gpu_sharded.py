@@ -267,3 +267,32 @@ def test_block_cyclic_layout_reaches_the_reference_fixed_point(orc, name, world,
     assert abs(sb.compute_overlap() - r["overlap"]) < 1e-9
     bound = a["N"] * (max(r["cab"]) / a["N"]) ** 5 / 10.0
     assert abs(sb.compute_free_energy() - r["f"]) < max(2e-9, 2 * bound) * max(1.0, abs(r["f"]))
+
+
+def test_full_size_c3_two_shards_equal_one(S):
+    """the headline configuration (N=1e7, Q=4, c=10) cut into two shards with the chunked exchange and the fused send/receive
+    buffers: same iterates as one shard, seen through reductions (max difference, overlap, free energy, row sums)"""
+    from sbm_bp_amd import synth
+    from sbm_bp_amd.distributed import LocalComm, ShardedBP
+    N, Q = 10_000_000, 4
+    pairs, cin, cout = synth.planted_partition(N, Q, 10.0, 0.1, 2)
+    g = S.Graph.from_edges(pairs, N)
+    del pairs
+    row_ptr, nbr, _ = g.csr()
+    del g
+    tc = synth.true_conf(N, Q)
+    cab, na = synth.cab_matrix(Q, cin, cout), np.array([N // Q] * Q, dtype=np.uint32)
+    out = []
+    for w in (1, 2):
+        sb = ShardedBP.from_csr(row_ptr, nbr, Q, 0, LocalComm(w), n_chunks=4 if w > 1 else 1)
+        assert sb.fused
+        sb.init_messages_device(1234, tc)
+        sb.expand_bp_params(cab, na, 1.0)
+        d = [sb.sweep(1) for _ in range(3)]
+        out.append((d, sb.compute_overlap(), sb.compute_free_energy(), sb._row_sums()))
+        if w > 1:
+            assert sb.plans[0].n_halo > 3_000_000  # nearly every vertex is a boundary vertex at c = 10
+        del sb
+    (d1, o1, f1, r1), (d2, o2, f2, r2) = out
+    assert np.abs(np.array(d1) - np.array(d2)).max() < 1e-12 and abs(o1 - o2) < 1e-12
+    assert abs(f1 - f2) < 1e-10 * abs(f1) and np.abs(r1 - r2).max() < 1e-9 * N
