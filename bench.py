@@ -104,7 +104,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--converge", action="store_true", help="also report sweeps-to-converge at 5e-6 (untimed)")
+    ap.add_argument("--converge", action="store_true", default=True,
+                    help="also report sweeps-to-converge at 5e-6 (untimed, after the timed region; default on)")
+    ap.add_argument("--no-converge", dest="converge", action="store_false")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the sharded driver (torch.distributed collectives) even with one rank")
     ap.add_argument("--gather", default="auto", choices=["auto", "messages"],
