@@ -265,6 +265,9 @@ int sbmbp_shard_fe_partial(sbmbp_engine_t *e, int want_entropy);                
 int sbmbp_shard_fe_finish(sbmbp_engine_t *e, double *out /* f_site, f_edge, e_site, e_edge */);
 int sbmbp_shard_nonedge_partial(sbmbp_engine_t *e, int want_entropy, uint32_t *n_values, int *order);
 int sbmbp_shard_nonedge_finish(sbmbp_engine_t *e, int want_entropy, int order, double *out /* f_nonedge, e_nonedge */);
+/* exact non-edge term for small graphs: d_psi_all = marginals of ALL vertices, global row order (device); leaves 4 doubles
+ * in red (all-pairs f/e over (own i, every l), adjacent f/e): all-reduce, then f = (red[0]-red[2])/2N, e = (red[1]-red[3])/2N */
+int sbmbp_shard_nonedge_exact_partial(sbmbp_engine_t *e, const double *d_psi_all, int want_entropy);
 int sbmbp_shard_em_partial(sbmbp_engine_t *e, uint32_t *n_values);
 int sbmbp_shard_em_finish(sbmbp_engine_t *e, double *na_expect, double *nna_expect, double *cab_expect);
 

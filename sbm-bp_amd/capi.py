@@ -78,6 +78,7 @@ SYMBOLS = {
     "sbmbp_shard_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]),
     "sbmbp_shard_begin": (C.c_int, [C.c_void_p, C.c_double]),
     "sbmbp_shard_pack": (C.c_int, [C.c_void_p, C.c_uint32, c_u32p, C.c_uint32, c_dp, C.c_uint32]),
+    "sbmbp_shard_nonedge_exact_partial": (C.c_int, [C.c_void_p, c_dp, C.c_int]),
     "sbmbp_shard_set_exact": (C.c_int, [C.c_void_p, C.c_int]),
     "sbmbp_shard_set_io": (C.c_int, [C.c_void_p, c_u32p, c_u32p, c_dp, c_dp, c_dp, C.c_uint32]),
     "sbmbp_shard_unpack": (C.c_int, [C.c_void_p, C.c_uint32, c_dp, c_u32p, C.c_uint32, C.c_uint32]),

@@ -572,8 +572,8 @@ int nonedge_terms(sbmbp_engine *e, bool want_entropy, double out[2]) {
     if (exact) {
         const uint32_t g = (N + BLOCK - 1) / BLOCK;
         CHK(ensure_partials(e, size_t(g) * g * (NE_NP + 1)));
-        DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_exact<QQ>), dim3(g, g), dim3(BLOCK), 0, e->stream, e->d_psi[e->pcur], N, d_Pm,
-                                         d_cab, invN, int(want_entropy), e->d_partials));
+        DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_exact<QQ>), dim3(g, g), dim3(BLOCK), 0, e->stream, e->d_psi[e->pcur], N,
+                                         e->d_psi[e->pcur], N, d_Pm, d_cab, invN, int(want_entropy), e->d_partials));
         HIPCHK(hipGetLastError());
         CHK(fold_to_host(e, g * g, NE_NP, NE_NP + 1, all));
         CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (NE_NP + 1)));
@@ -1724,6 +1724,37 @@ int sbmbp_shard_nonedge_partial(sbmbp_engine_t *e, int want_entropy, uint32_t *n
     CHK(fold_to_device(e, e->n_blk, NE_NP, NE_NP + 1, e->d_red + T));
     *n_values = uint32_t(T) + 2;
     *order = K;
+    return SBMBP_OK;
+}
+
+// Exact non-edge term on shards (small graphs, where the moment series is not accurate enough): d_psi_all = the marginals
+// of ALL vertices in global row order (the caller all-reduces the shards' own rows into it). Leaves in red[0..4)
+// {all-pairs f, all-pairs e, adjacent f, adjacent e} over (own i, every l); after a SUM all-reduce of the 4 values
+// f_nonedge = (red[0] - red[2]) / 2N, e_nonedge = (red[1] - red[3]) / 2N   (bp.cpp:675-741).
+int sbmbp_shard_nonedge_exact_partial(sbmbp_engine_t *e, const double *d_psi_all, int want_entropy) {
+    IS_SHARD(e);
+    if (!d_psi_all) return SBMBP_ERR_ARG;
+    const uint32_t Q = e->Q;
+    if (e->dc != 0) { HIPCHK(hipMemsetAsync(e->d_red, 0, 4 * 8, e->stream)); return SBMBP_OK; }
+    std::vector<double> mats;
+    double wmax;
+    shard_nonedge_mats(e, mats, wmax);
+    if (!e->d_mats) CHK(dev_alloc(e, &e->d_mats, 3 * Q * Q));
+    HIPCHK(hipMemcpyAsync(e->d_mats, mats.data(), mats.size() * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const double *d_Pm = e->d_mats + Q * Q, *d_cab = e->d_mats + 2 * Q * Q;
+    const double invN = 1.0 / double(e->Nglob);
+    const uint32_t gi = (e->N + BLOCK - 1) / BLOCK, gl = (e->Nglob + BLOCK - 1) / BLOCK;
+    CHK(ensure_partials(e, size_t(gi) * gl * (NE_NP + 1)));
+    DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_exact<QQ>), dim3(gi, gl), dim3(BLOCK), 0, e->stream, e->d_psi[e->pcur], e->N, d_psi_all,
+                                     e->Nglob, d_Pm, d_cab, invN, want_entropy, e->d_partials));
+    HIPCHK(hipGetLastError());
+    CHK(fold_to_device(e, gi * gl, NE_NP, NE_NP + 1, e->d_red));
+    CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (NE_NP + 1)));
+    DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_exact_adj<QQ>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
+                                     e->d_psi[e->pcur], d_Pm, d_cab, e->d_blk_row, invN, want_entropy, e->d_partials));
+    HIPCHK(hipGetLastError());
+    CHK(fold_to_device(e, e->n_blk, NE_NP, NE_NP + 1, e->d_red + 2));
     return SBMBP_OK;
 }
 

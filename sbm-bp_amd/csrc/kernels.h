@@ -1600,14 +1600,16 @@ k_fold_rows_sum(const double *__restrict__ in, uint32_t rows, uint32_t cols, uin
 // ------------------------------------------------------------------------------------------------
 template <int Q>
 __global__ void __launch_bounds__(BLOCK)
-k_nonedge_exact(const double *__restrict__ psi, uint32_t n, const double *__restrict__ Pmat /* Q*Q */,
+k_nonedge_exact(const double *__restrict__ psi /* rows i: n of them (a shard: its own rows) */, uint32_t n,
+                const double *__restrict__ psi_l /* rows l: n_l of them (all vertices) */, uint32_t n_l,
+                const double *__restrict__ Pmat /* Q*Q */,
                 const double *__restrict__ cab, double invN, int want_entropy, double *__restrict__ partials) {
     __shared__ double sl[BLOCK * Q];
     __shared__ double sred[4 * (NE_NP + 1)];
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t l0 = blockIdx.y * BLOCK;
-    const uint32_t cnt = min(uint32_t(BLOCK), n - l0);
-    for (uint32_t x = threadIdx.x; x < cnt * Q; x += BLOCK) sl[x] = psi[size_t(l0) * Q + x];
+    const uint32_t cnt = min(uint32_t(BLOCK), n_l - l0);
+    for (uint32_t x = threadIdx.x; x < cnt * Q; x += BLOCK) sl[x] = psi_l[size_t(l0) * Q + x];
     __syncthreads();
     double acc[NE_NP] = {0.0, 0.0};
     if (i < n) {

@@ -22,6 +22,7 @@ import numpy as np
 from sbm_bp_amd.plan import ShardPlan, block_cyclic_layout, busiest_link_rows, partition_rows, permute_csr
 
 HINT_SCALE = 8.0  # same rule as run_sweeps in csrc/engine.hip
+EXACT_NONEDGE_MAX = 32768  # up to this many vertices the non-edge term is the exact all-pairs sum (engine.hip: nonedge_terms)
 
 
 class ShardDesc(C.Structure):
@@ -159,6 +160,16 @@ class HipShardBackend:
         n, k = C.c_uint32(0), C.c_int(0)
         self._check(self._lib.sbmbp_shard_nonedge_partial(self._h, int(want_entropy), C.byref(n), C.byref(k)))
         return n.value, k.value
+
+    def own_rows_in_global_table(self, n_global):
+        """a zero (n_global, Q) table with this shard's current marginals at their global rows (to be SUM all-reduced)"""
+        t = self.torch.zeros((n_global, self.Q), dtype=self.torch.float64, device=self.device)
+        p = self.plan
+        t[p.row0:p.row0 + p.n_own] = self.psi[self.read_buffer(0)][:p.n_own]
+        return t
+
+    def nonedge_exact_partial(self, psi_all, want_entropy):
+        self._check(self._lib.sbmbp_shard_nonedge_exact_partial(self._h, C.cast(psi_all.data_ptr(), C.POINTER(C.c_double)), int(want_entropy)))
 
     def nonedge_finish(self, want_entropy, order):
         out = np.zeros(2)
@@ -615,6 +626,19 @@ class ShardedBP:
             sh.fe_partial(want_entropy)
         self._reduce(5, 0)
         fe = [sh.fe_finish() for sh in self.shards][0]
+        if self.dc == 0 and self.N_global <= EXACT_NONEDGE_MAX and all(hasattr(sh, "nonedge_exact_partial") for sh in self.shards):
+            # small graphs: the O(N^2) loop of the reference, exactly (as the single engine does): every shard gets the
+            # marginals of all vertices (own rows all-reduced into a global table) and sums its own rows against them
+            tabs = [sh.own_rows_in_global_table(self.N_global) for sh in self.shards]
+            self.comm.all_reduce(tabs, "sum")
+            for sh, t in zip(self.shards, tabs):
+                sh.nonedge_exact_partial(t, want_entropy)
+            self._reduce(4, 0)
+            for sh in self.shards:
+                sh.sync()
+            v = self.shards[0].red[:4].cpu().numpy()
+            two_n = 2.0 * self.N_global
+            return fe, np.array([(v[0] - v[2]) / two_n, (v[1] - v[3]) / two_n])
         nk = [sh.nonedge_partial(want_entropy) for sh in self.shards]
         n, order = nk[0]
         if n:
