@@ -318,7 +318,7 @@ int message_diff(sbmbp_engine *e, double *out) {
     if (n == 0) { *out = 0.0; return SBMBP_OK; }
     const uint32_t nb = uint32_t(std::min<uint64_t>(2048, (n + BLOCK - 1) / BLOCK));
     CHK(ensure_partials(e, size_t(nb) * 2));
-    hipLaunchKernelGGL(k_msg_diff, dim3(nb), dim3(BLOCK), 0, e->stream, e->d_M[0], e->d_M[1], n, int(e->Q) - 1, e->d_partials);
+    DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_msg_diff<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_M[0], e->d_M[1], n, e->d_partials));
     hipLaunchKernelGGL(k_fold_stage, dim3(1), dim3(BLOCK), 0, e->stream, e->d_partials, nb, nb, 1, 1, 2u, e->d_stage);
     HIPCHK(hipGetLastError());
     double r[2];
@@ -1568,7 +1568,7 @@ int sbmbp_shard_msgdiff_partial(sbmbp_engine_t *e) {
     if (n == 0) { HIPCHK(hipMemsetAsync(e->d_red, 0, 8, e->stream)); return SBMBP_OK; }
     const uint32_t nb = uint32_t(std::min<uint64_t>(2048, (n + BLOCK - 1) / BLOCK));
     CHK(ensure_partials(e, size_t(nb) * 2));
-    hipLaunchKernelGGL(k_msg_diff, dim3(nb), dim3(BLOCK), 0, e->stream, e->d_M[0], e->d_M[1], n, int(e->Q) - 1, e->d_partials);
+    DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_msg_diff<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_M[0], e->d_M[1], n, e->d_partials));
     hipLaunchKernelGGL(k_fold_stage, dim3(1), dim3(BLOCK), 0, e->stream, e->d_partials, nb, nb, 1, 1, 2u, e->d_stage);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(e->d_red, e->d_stage + 1, 8, hipMemcpyDeviceToDevice, e->stream));

@@ -1071,16 +1071,16 @@ k_unpack_rows(const double *__restrict__ in, uint32_t n, int Q, int ncomp, doubl
 }
 
 // exact 1-step criterion of converge (bp.cpp:1059-1063): max over all message entries |a - b| (records decoded)
+template <int Q>
 __global__ void __launch_bounds__(BLOCK)
-k_msg_diff(const double *__restrict__ a, const double *__restrict__ b, uint64_t n_msg, int mc, double *__restrict__ partials) {
+k_msg_diff(const double *__restrict__ a, const double *__restrict__ b, uint64_t n_msg, double *__restrict__ partials) {
     __shared__ double sred[4 * 2];
     double md = 0.0;
-    const int Q = mc + 1;
     for (uint64_t k = uint64_t(blockIdx.x) * BLOCK + threadIdx.x; k < n_msg; k += uint64_t(gridDim.x) * BLOCK) {
-        double wa[QMAX], wb[QMAX], va[QMAX], vb[QMAX];
-        for (int q = 0; q < mc; ++q) { wa[q] = a[k * mc + q]; wb[q] = b[k * mc + q]; }
-        decode_msg_rt(wa, Q, va);
-        decode_msg_rt(wb, Q, vb);
+        double va[Q], vb[Q];
+        load_msg<Q>(a, size_t(k), va);
+        load_msg<Q>(b, size_t(k), vb);
+#pragma unroll
         for (int q = 0; q < Q; ++q) md = nanmax(md, fabs(va[q] - vb[q]));
     }
     double dummy[1] = {0.0};
