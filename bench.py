@@ -6,22 +6,25 @@ resident in HBM. Default workload: the configuration the north-star target is qu
 N=1e7, Q=4, c=10 (BASELINE configs[2]; it fits one MI355X). Other workloads: --workload C2|C4|C5|small.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...            # bare shell: starts its own N ranks (one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task description): value = whole-job edge-message
-updates per second; roofline = algorithmic bytes per sweep / HIP-event time of the sweep kernel;
-cpu_baseline = the reference's converge() (oracle/_ref/bp_ref, or the oracle port) on a bounded
-sample of the same graph family, timed on this box's host cores.
+updates per second over the timed steady-state sweeps; `converge` = one converge(5e-6) from the initial
+state timed between barriers (the metric as SURVEY 8(d) words it: sweeps x E2 / wall time of the converge
+phase); roofline = algorithmic bytes per sweep / HIP-event time of the sweep kernel; cpu_baseline = the
+reference's converge() (oracle/_ref/bp_ref, or the oracle port) on a bounded sample of the same graph
+family, timed on this box's host cores.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -38,10 +41,36 @@ WORKLOADS = {
     "C4": (1_000_000, 8, 8.0, 0.1, 1, 3),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+CONV_CRIT = 5e-6       # the reference's default -e (main.cpp:113)
 
 
-def cpu_baseline(Q, c, eps, sample_n=200_000, sweeps=8):
-    """reference converge() on one host core, on a bounded sample of the same graph family"""
+def source_sha():
+    """identifies the kernel sources a number was measured on (the GPU box has no .git): profiles/*.json carry it"""
+    h = hashlib.sha256()
+    for f in ("kernels.h", "engine.hip", "dist.hip", "host_graph.cpp"):
+        p = os.path.join(ROOT, "sbm-bp_amd", "csrc", f)
+        if os.path.exists(p):
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def host_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"nproc": os.cpu_count(), "cpu_model": model}
+
+
+def cpu_baseline(Q, c, eps, sample_n=1_000_000, sweeps=4):
+    """the reference's converge() on ONE host core (the reference is single-threaded), on a bounded sample of the
+    same graph family (same Q, c, eps at N = 1e6: the reference needs ~220 B of heap per directed edge and 50-70 s per
+    sweep at the benchmarked N = 1e7)"""
+    import numpy as np
     from sbm_bp_amd import synth
     pairs, cin, cout = synth.planted_partition(sample_n, Q, c, eps, 12345)
     e2 = 2 * len(pairs)
@@ -52,6 +81,7 @@ def cpu_baseline(Q, c, eps, sample_n=200_000, sweeps=8):
     for r in range(Q):
         for s in range(r, Q):
             cabu.append(cin if r == s else cout)
+    host = host_info()
     if os.path.exists(ref_bin) and os.access(ref_bin, os.X_OK):
         with tempfile.TemporaryDirectory() as d:
             path = os.path.join(d, "sample.bin")
@@ -62,7 +92,8 @@ def cpu_baseline(Q, c, eps, sample_n=200_000, sweeps=8):
                     "d=0", "e=0", "t=%d" % sweeps, "quiet=1"]
             out = subprocess.run(argv, capture_output=True, text=True, check=True).stdout
             r = json.loads(out)
-            return {"value": r["edge_msg_per_s"], "unit": "edge-msg/s", "cores": 1, "kind": "reference", "sample": sample}
+            return {"value": r["edge_msg_per_s"], "unit": "edge-msg/s", "cores": 1, "kind": "reference", "sample": sample,
+                    "host": host}
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     g = orc.Graph.from_edges(pairs, sample_n)
@@ -73,7 +104,7 @@ def cpu_baseline(Q, c, eps, sample_n=200_000, sweeps=8):
     t0 = time.perf_counter()
     bp.converge_async(0.0, sweeps, 1.0, rng)
     dt = time.perf_counter() - t0
-    return {"value": sweeps * g.E2 / dt, "unit": "edge-msg/s", "cores": 1, "kind": "port", "sample": sample}
+    return {"value": sweeps * g.E2 / dt, "unit": "edge-msg/s", "cores": 1, "kind": "port", "sample": sample, "host": host}
 
 
 def pmc_traffic(workload, kernel, n_gpus, E2, N, Q):
@@ -81,20 +112,63 @@ def pmc_traffic(workload, kernel, n_gpus, E2, N, Q):
     (profiles/*_pmc_*.json; bench.py cannot collect PMC counters itself). Corrected as
     MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 wide coalesced
     streaming reads are tallied at half (128-B requests counted as 64 B), random 32-B gathers cost one
-    64-B request each and are counted in full; writes read exactly. See DESIGN.md §4."""
+    64-B request each and are counted in full; writes read exactly. See DESIGN.md §4.
+    Returns (traffic or None, note): the summary is only used when it was collected on THESE kernel sources."""
     import glob
     if n_gpus != 1:
-        return None
+        return None, None
+    sha = source_sha()
+    stale = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json")), reverse=True):
         try:
             d = json.load(open(path))
         except Exception:
             continue
         if d.get("kernel") == kernel and d.get("workload", "").startswith(workload + " "):
+            if d.get("source_sha") != sha:
+                stale = stale or "%s was collected on kernel sources %s, this build is %s" % (
+                    os.path.relpath(path, ROOT), d.get("source_sha", "(unrecorded)"), sha)
+                continue
             c = d["counters"]
             stream_reads = E2 * (8.0 * (Q - 1) + 4.0) + N * 4.0  # own old message record (Q-1 components) + index per edge, row offsets
-            return c["FETCH_SIZE"]["per_launch_mean"] * 1024.0 + 0.5 * stream_reads + c["WRITE_SIZE"]["per_launch_mean"] * 1024.0
-    return None
+            return (c["FETCH_SIZE"]["per_launch_mean"] * 1024.0 + 0.5 * stream_reads + c["WRITE_SIZE"]["per_launch_mean"] * 1024.0,
+                    "from %s (same kernel sources)" % os.path.relpath(path, ROOT))
+    return None, stale
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` from a bare shell: start N fresh rank processes (one per GPU) with the environment
+    torch.distributed.run would give them. This parent never touches the GPU and never re-execs itself; rank 0's JSON
+    line reaches stdout through the inherited descriptor."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SBMBP_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+            if p.returncode != 0:  # one rank failed: the others would wait for it in a collective
+                for q in procs:
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    return rc
 
 
 def main():
@@ -105,14 +179,20 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--converge", action="store_true", default=True,
-                    help="also report sweeps-to-converge at 5e-6 (untimed, after the timed region; default on)")
+                    help="also time one converge(5e-6) from the initial state (after the timed sweeps; default on)")
     ap.add_argument("--no-converge", dest="converge", action="store_false")
     ap.add_argument("--force-sharded", action="store_true",
-                    help="run the sharded driver (torch.distributed collectives) even with one rank")
+                    help="run the sharded driver (RCCL collectives) even with one rank")
     ap.add_argument("--gather", default="auto", choices=["auto", "messages"],
                     help="sweep form: auto = marginal-gather when exact, messages = always gather messages")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="ranks rendezvous, build their shard plans and cross-check them; no GPU work, no measurement")
     args = ap.parse_args()
 
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -120,18 +200,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # SBMBP_REHEARSAL=1 (development aid, never the measured configuration): all ranks share cuda:0 and the
     # collectives go over gloo through host memory, so the multi-process driver can run on a 1-GPU box
-    rehearsal = os.environ.get("SBMBP_REHEARSAL", "0") == "1"
+    rehearsal = os.environ.get("SBMBP_REHEARSAL", "0") == "1" or args.dry_run
     if rehearsal:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
     sharded = world > 1 or args.force_sharded
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    if not args.dry_run:
+        torch.cuda.set_device(local_rank)
     if sharded:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -142,7 +222,10 @@ def main():
     S.load_library()
 
     N, Q, c, eps, dc, gseed = WORKLOADS[args.workload]
+    if args.dry_run:
+        return dry_run(args, rank, world, N, Q, c, eps, dc, gseed)
     t0 = time.perf_counter()
+    tc = synth.true_conf(N, Q)
     if not sharded:
         if args.workload == "C4":
             pairs, cab_mat, c_eff = synth.dc_sbm_powerlaw(N, Q, c, eps, gseed)
@@ -153,22 +236,38 @@ def main():
         del pairs
         bm = S.blockmodel_t(g, Q, dc)
         bp = S.bp_conditional(device=local_rank)
-        bp.init_messages_device(bm, synth.true_conf(N, Q), 1234)
-        bp.expand_bp_params(S.bp_blockmodel_state(cab_mat, np.array(synth.group_sizes(N, Q), dtype=np.uint32)))
+        bp.init_messages_device(bm, tc, 1234)
+        state = S.bp_blockmodel_state(cab_mat, np.array(synth.group_sizes(N, Q), dtype=np.uint32))
+        bp.expand_bp_params(state)
         if args.gather == "messages":
             bp.set_gather_mode(1)
         E2_total = g.E2
         runner = bp
+
+        def reinit():
+            bp.reinit_messages_device(tc, 1234)
+            bp.expand_bp_params(state)
     else:
         from sbm_bp_amd.distributed import ShardedBP, HostStagedComm
         runner = ShardedBP.synthetic(N, Q, c, eps, gseed, dc=dc, seed=1234, comm=HostStagedComm() if rehearsal else None)
         E2_total = runner.E2_global
+
+        def reinit():
+            runner.init_messages_device(1234, tc)
+            runner.expand_bp_params(runner.cab, runner.na, 1.0)
     setup_s = time.perf_counter() - t0
 
     def barrier():
         if sharded:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if not sharded:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     runner.set_timing(False)
     runner.sweep(args.warmup, 1.0, want_diff=False)
@@ -178,25 +277,33 @@ def main():
     t1 = time.perf_counter()
     runner.sweep(args.steps, 1.0, want_diff=False)
     barrier()
-    dt = time.perf_counter() - t1
-    if sharded:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t1)
     st = runner.stats()
     phases = runner.phase_times() if sharded else None
     kernel_ms = st.sweep_kernel_ms / max(1, st.sweep_launches)
     bytes_per_launch = st.bytes_per_sweep  # this rank's rows/edges: what ONE launch of k_sweep processes
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
 
-    sweeps_to_converge = None
+    converge = None
     if args.converge:
+        # the metric as SURVEY 8(d) defines it: the whole converge phase from the initial state, host loop included
         runner.set_timing(False)
-        niter, _ = runner.converge(5e-6, 1000, 1.0)
-        sweeps_to_converge = (args.warmup + args.steps + niter + 1) if niter >= 0 else -1
+        reinit()
+        barrier()
+        t2 = time.perf_counter()
+        niter, _ = runner.converge(CONV_CRIT, 1000, 1.0)
+        barrier()
+        dtc = max_over_ranks(time.perf_counter() - t2)
+        sweeps = niter + 1 if niter >= 0 else 1000
+        converge = {"crit": CONV_CRIT, "sweeps": sweeps, "converged": niter >= 0, "wall_ms": dtc * 1e3,
+                    "edge_msg_per_s": sweeps * E2_total / dtc, "ms_per_sweep": dtc * 1e3 / sweeps}
 
     if rank == 0:
         kname = ("k_sweep_psi<%d>" if st.psi_form_sweeps else "k_sweep<%d>") % Q
+        traffic, traffic_note = pmc_traffic(args.workload, kname, world, E2_total, N, Q)
+        # the marginal-gather kernel's OWN minimum bytes (Q-1-component records, neighbour index instead of a reverse
+        # index): stated next to SURVEY's work-unit figure, which `achieved` / `frac` use
+        own_bytes = E2_total / world * (2 * 8.0 * (Q - 1) + 8.0 * Q + 4.0) + N / world * (8.0 * Q + 4.0) if st.psi_form_sweeps else None
         out = {
             "metric": "BP edge-message updates/sec", "value": args.steps * E2_total / dt, "unit": "edge-msg/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
@@ -205,11 +312,18 @@ def main():
                 args.workload, N, Q, c, eps, dc), "N": N, "Q": Q, "E2": int(E2_total), "hub_rows": int(st.n_hub_rows), "parallelism": "vertex-range shards x%d%s" % (world, " (sharded driver)" if sharded else ""),
                 "setup_s": round(setup_s, 2)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.workload, kname, world, E2_total, N, Q),
-                         "kernel": kname, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": kname, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "frac_uses": "SURVEY 8(d) bytes per sweep: E2(24Q+4) + N(8Q+8)",
+                         "kernel_min_bytes_per_launch": own_bytes},
+            "build": {"source_sha": source_sha()},
         }
+        if own_bytes and kernel_ms > 0:
+            out["roofline"]["frac_of_kernel_min_bytes"] = own_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if traffic_note:
+            out["roofline"]["traffic_source" if traffic is not None else "traffic_stale"] = traffic_note
         if sharded:  # what rank 0 ships per sweep: the numbers needed to read a multi-GPU result
+            out["n_ranks_seen"] = dist.get_world_size()
             p0, sh0 = runner.plans[0], runner.shards[0]
             per_peer = p0.send_counts.astype(float) * sh0.ncomp * 8 / 1e6
             out["config"]["exchange"] = {"chunks": int(p0.n_chunks), "payload_components": int(sh0.ncomp),
@@ -219,14 +333,45 @@ def main():
                 out["config"]["exchange"]["rank0_ms_per_sweep"] = {k: round(v, 4) for k, v in phases.items() if k != "sweeps"}
         if rehearsal:
             out["rehearsal"] = "ranks share cuda:0, gloo collectives staged through the host: not a measurement"
-        if sweeps_to_converge is not None:
-            out["sweeps_to_converge"] = sweeps_to_converge
+        if converge is not None:
+            out["converge"] = converge
+            out["sweeps_to_converge"] = converge["sweeps"] if converge["converged"] else -1
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(Q, c, eps)  # plain planted partition of the same Q, c (also for C4)
         print(json.dumps(out), flush=True)
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def dry_run(args, rank, world, N, Q, c, eps, dc, gseed):
+    """no GPU: every rank builds its shard plan of a small graph of the workload's family and the ranks cross-check what
+    they will send each other (rank r's send count to p must be rank p's receive count from r)"""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import sbm_bp_amd as S
+    from sbm_bp_amd import synth
+    from sbm_bp_amd.plan import ShardPlan, partition_rows
+    n = min(N, 200_000)
+    pairs, _, _ = synth.planted_partition(n, Q, c, eps, gseed)
+    row_ptr, nbr, _ = S.Graph.from_edges(pairs, n).csr()
+    plan = ShardPlan(row_ptr, nbr, partition_rows(row_ptr, world), rank, 2)
+    ok = True
+    if world > 1:
+        mine = torch.tensor(np.concatenate([plan.send_counts, plan.recv_counts]), dtype=torch.int64)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        for p in range(world):
+            ok = ok and int(allv[p][world + rank]) == int(plan.send_counts[p])  # what p expects from me
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
+                          "plans_consistent": bool(ok), "sample_N": n, "halo_rows_rank0": int(plan.n_halo)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

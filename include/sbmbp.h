@@ -169,6 +169,11 @@ typedef struct sbmbp_learn_result {
 } sbmbp_learn_result;
 int sbmbp_learning(sbmbp_engine_t *e, float learning_conv_crit, uint32_t learning_max_time, float learning_rate,
                    float dumping_rate, sbmbp_learn_result *out);
+/* Two schedule rules of the EM loop (no reference counterpart). field_mix: relaxation of the global
+ * field inside the BP runs of the EM loop (default 0.3; the smaller of this and sbmbp_set_schedule's value is used; 1 =
+ * plain Jacobi). snap: the integer truncation of the group sizes (belief_propagation.cpp:58-63) treats a value within
+ * min(snap * N * learning_conv_crit, 0.01) BELOW an integer as that integer (default snap = 1; 0 = truncate exactly). */
+int sbmbp_set_learning_schedule(sbmbp_engine_t *e, double field_mix, double snap);
 
 /* counters for the metric "BP edge-message updates per second" */
 typedef struct sbmbp_stats {
@@ -214,16 +219,18 @@ typedef struct sbmbp_shard_desc {
 } sbmbp_shard_desc;
 
 typedef struct sbmbp_conv_state {
-    double maxdiff; /* hint of the last executed sweep (2-step message difference) */
-    int conv_iter;  /* first sweep whose hint fell below the armed threshold, or -1 */
+    double maxdiff; /* of the last executed sweep: the 1-step message difference if last_exact, else the 2-step hint */
+    int conv_iter;  /* first sweep whose 1-step difference fell below the criterion, or -1 */
     int sweep_idx;  /* sweeps executed since sbmbp_shard_begin */
     int stop;       /* queued sweeps after the trigger were skipped */
-    int reserved;
+    int last_exact;
 } sbmbp_conv_state;
 
 int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *desc, uint32_t Q, uint32_t deg_corr_flag, int device);
-/* start a run of sweeps: uploads parameters, arms the device-side stop flag at `armed_crit` (< 0: never) */
-int sbmbp_shard_begin(sbmbp_engine_t *e, double armed_crit);
+/* start a run of sweeps: uploads parameters and the convergence criterion (< 0: never converges). The sweeps report
+ * 2-step hints until one falls below 8 * crit; from then on they report the reference's 1-step difference and the
+ * device-side stop flag works on it (all on the device: no host round trip) */
+int sbmbp_shard_begin(sbmbp_engine_t *e, double crit);
 /* gather rows idx[0..n) of the marginal table that sweep j READS into out (device pointers), ncomp
  * components per row: Q, or Q-1 to ship the marginals without their last component (they sum to 1) */
 int sbmbp_shard_pack(sbmbp_engine_t *e, uint32_t j, const uint32_t *d_idx, uint32_t n, double *d_out, uint32_t ncomp);
@@ -248,7 +255,8 @@ int sbmbp_shard_sweep_partial(sbmbp_engine_t *e, uint32_t j);
  * chunk c+1 runs), then one fold of all chunks' partials into red */
 int sbmbp_shard_sweep_chunk(sbmbp_engine_t *e, uint32_t j, uint32_t c);
 int sbmbp_shard_sweep_fold(sbmbp_engine_t *e);
-/* consume the reduction values: n_rows rows of (Q+1) doubles starting at red + 16 (the caller
+#define SBMBP_RED_GATHER_OFFSET 32 /* > SBMBP_MAX_Q: the gathered rows never overlap the shard's own red[0..Q] */
+/* consume the reduction values: n_rows rows of (Q+1) doubles starting at red + SBMBP_RED_GATHER_OFFSET (the caller
  * all-gathers every shard's red[0..Q] there; n_rows = number of shards). Rows are folded in order —
  * sums for the Q field entries, max for the hint. mode 0 after a sweep, 1 field initialisation */
 int sbmbp_shard_finalize(sbmbp_engine_t *e, int mode, uint32_t n_rows);
@@ -275,12 +283,6 @@ int sbmbp_shard_em_finish(sbmbp_engine_t *e, double *na_expect, double *nna_expe
 int sbmbp_shard_poll(sbmbp_engine_t *e, sbmbp_conv_state *out);
 /* after a poll: `executed` sweeps of the queued batch really ran; flips the buffer parities */
 int sbmbp_shard_commit(sbmbp_engine_t *e, uint32_t executed);
-/* on: the sweep chunks report the exact 1-step message difference (they read the other message buffer as well) instead
- * of the 2-step hint, so a stop flag armed at the real criterion ends the run exactly where the reference's test does */
-int sbmbp_shard_set_exact(sbmbp_engine_t *e, int on);
-/* re-arm after a trigger whose exact check failed: clears stop, sets the threshold */
-int sbmbp_shard_rearm(sbmbp_engine_t *e, double armed_crit);
-
 #ifdef __cplusplus
 }
 #endif

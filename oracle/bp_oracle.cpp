@@ -804,12 +804,13 @@ void em_expect(bp_t &s) {
         }
 }
 
-// learning_step (:53-75)
-void learning_step(bp_t &s, float learning_rate) {
+// learning_step (:53-75). snap = 0 is the reference; the synchronous EM run of the engine treats a value within snap
+// below an integer as that integer (include/sbmbp.h: sbmbp_set_learning_schedule).
+void learning_step(bp_t &s, float learning_rate, double snap = 0.0) {
     uint32_t Q = s.Q;
     auto _N = s.N;
     for (uint32_t i = 0; i + 1 < Q; ++i) {
-        s.na[i] = unsigned(int(learning_rate * s.na_expect[i] + (1.0 - learning_rate) * s.na[i]));
+        s.na[i] = unsigned(int(learning_rate * s.na_expect[i] + (1.0 - learning_rate) * s.na[i] + snap));
         _N -= s.na[i];
     }
     s.na[Q - 1] = _N;
@@ -963,6 +964,10 @@ int orc_bp_learning(void *sp, float learning_conv_crit, unsigned learning_max_ti
     auto &s = *static_cast<bp_t *>(sp);
     double fold = 0.0, fdiff = 1.0;
     int steps = 0;
+    // the two rules of the engine's synchronous EM loop (sbmbp_set_learning_schedule defaults): field relaxation 0.3
+    // inside the BP runs, and the snap tolerance min(N * crit, 0.01) of the group-size truncation
+    const double keep_mix = s.field_mix;
+    if (sync) { s.field_mix = std::min(s.field_mix, 0.3); s.Sprev.clear(); }
     for (unsigned t = 0; t < learning_max_time; ++t) {
         if (fdiff < learning_conv_crit) learning_conv_crit *= 0.1;
         if (sync) converge_sync(s, learning_conv_crit, learning_max_time, dumping_rate, nullptr);
@@ -973,9 +978,10 @@ int orc_bp_learning(void *sp, float learning_conv_crit, unsigned learning_max_ti
         fold = fnew;
         if (std::isnan(fold) || std::isinf(fold)) break;
         if (fdiff < learning_conv_crit) break;
-        learning_step(s, learning_rate);
+        learning_step(s, learning_rate, sync ? std::min(1.0 * double(s.N) * double(learning_conv_crit), 0.01) : 0.0);
         ++steps;
     }
+    s.field_mix = keep_mix;
     if (f_out) *f_out = fold;
     return steps;
 }

@@ -195,6 +195,11 @@ class BeliefPropagation:
         tc = np.ascontiguousarray(true_conf, dtype=np.uint32)
         check(self._lib.sbmbp_init_messages_device(self._h, seed, tc.ctypes.data_as(c_u32p)))
 
+    def reinit_messages_device(self, true_conf, seed):
+        """the same device-side initial state again on the existing engine (no reallocation)"""
+        tc = np.ascontiguousarray(true_conf, dtype=np.uint32)
+        check(self._lib.sbmbp_init_messages_device(self._h, seed, tc.ctypes.data_as(c_u32p)))
+
     def init_special_needs(self, if_output_marginals):
         self.if_output_marginals_ = bool(if_output_marginals)
 
@@ -213,6 +218,10 @@ class BeliefPropagation:
     def set_gather_mode(self, mode=0):
         """0 = automatic (marginal-gather sweep when exact), 1 = always gather messages"""
         check(self._lib.sbmbp_set_gather_mode(self._h, mode))
+
+    def set_learning_schedule(self, field_mix=0.3, snap=1.0):
+        """field relaxation inside the EM loop's BP runs and the snap tolerance of the group-size truncation (sbmbp.h)"""
+        check(self._lib.sbmbp_set_learning_schedule(self._h, field_mix, snap))
 
     def set_nonedge_mode(self, mode=0, series_order=0):
         check(self._lib.sbmbp_set_nonedge_mode(self._h, mode, series_order))

@@ -61,6 +61,7 @@ SYMBOLS = {
     "sbmbp_get_field": (C.c_int, [C.c_void_p, c_dp]),
     "sbmbp_set_schedule": (C.c_int, [C.c_void_p, C.c_double, C.c_uint32]),
     "sbmbp_set_gather_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "sbmbp_set_learning_schedule": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "sbmbp_converge": (C.c_int, [C.c_void_p, C.c_double, C.c_uint32, C.c_double, C.POINTER(C.c_int), c_dp]),
     "sbmbp_sweep": (C.c_int, [C.c_void_p, C.c_double, C.c_uint32, c_dp]),
     "sbmbp_free_energy": (C.c_int, [C.c_void_p, c_dp, c_dp]),
@@ -79,7 +80,6 @@ SYMBOLS = {
     "sbmbp_shard_begin": (C.c_int, [C.c_void_p, C.c_double]),
     "sbmbp_shard_pack": (C.c_int, [C.c_void_p, C.c_uint32, c_u32p, C.c_uint32, c_dp, C.c_uint32]),
     "sbmbp_shard_nonedge_exact_partial": (C.c_int, [C.c_void_p, c_dp, C.c_int]),
-    "sbmbp_shard_set_exact": (C.c_int, [C.c_void_p, C.c_int]),
     "sbmbp_shard_set_io": (C.c_int, [C.c_void_p, c_u32p, c_u32p, c_dp, c_dp, c_dp, C.c_uint32]),
     "sbmbp_shard_unpack": (C.c_int, [C.c_void_p, C.c_uint32, c_dp, c_u32p, C.c_uint32, C.c_uint32]),
     "sbmbp_shard_read_buffer": (C.c_int, [C.c_void_p, C.c_uint32]),
@@ -98,7 +98,6 @@ SYMBOLS = {
     "sbmbp_shard_em_finish": (C.c_int, [C.c_void_p, c_dp, c_dp, c_dp]),
     "sbmbp_shard_poll": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sbmbp_shard_commit": (C.c_int, [C.c_void_p, C.c_uint32]),
-    "sbmbp_shard_rearm": (C.c_int, [C.c_void_p, C.c_double]),
 }
 
 _LIB = None

@@ -38,7 +38,19 @@ struct dev_params {
     int sweep_idx;             // sweeps executed in the current converge call
     int stop;                  // 1: queued sweeps that follow are no-ops
     int have_prev;             // S holds a previous value (field relaxation)
+    // Convergence test of the marginal-gather sweeps. Their in-kernel difference is the 2-step value |m^{t+1} - m^{t-1}|
+    // (a hint: the kernel only holds its own previous message). hinted = 1 declares that; once the hint falls below
+    // HINT_SCALE * crit, k_finalize sets exact = 1 and from the next sweep on the kernels read the other message buffer
+    // too and report the reference's 1-step difference (bp.cpp:1059-1063), on which the stop flag then works.
+    int hinted;
+    int exact;
+    int last_exact;            // maxdiff of the last executed sweep is a 1-step difference (not a hint)
+    int pad_;
 };
+// With linear convergence at rate r the 2-step difference is (1 + 1/r) times the 1-step one, so exact mode is armed at
+// HINT_SCALE * crit: the first sweep whose 1-step difference is below crit is then already an exact-mode sweep unless
+// r < 1/(HINT_SCALE - 1), and the returned niter equals the explicit form's.
+constexpr double HINT_SCALE = 8.0;
 
 // tunables (A/B'd on MI355X, see DESIGN.md "Tuning log")
 #ifndef SBMBP_EPT_LO
@@ -723,8 +735,10 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
             const double *__restrict__ psi_old, double *__restrict__ psi_new, const uint32_t *__restrict__ blk_row,
             const uint32_t *__restrict__ blk_e0, const dev_params *__restrict__ P, int dc, double *__restrict__ partials,
             const int32_t *__restrict__ clamp, shard_io io, uint32_t n_seg /* segments = workgroups with work */, int xcd_order,
-            const double *__restrict__ Mcmp /* null: report the 2-step difference against the own previous message;
-                                               else the other message buffer (m^t): report the exact 1-step difference */) {
+            const double *__restrict__ Mcmp /* the other message buffer (m^t): read only while P->exact, to report the
+                                               exact 1-step difference instead of the 2-step one against the own previous message */,
+            int first_from_psi /* sweep 0 after a device initialisation: the incoming message IS the neighbour's marginal
+                                  (messages were initialised to the sender's marginal), no reconstruction */) {
     constexpr int EPT = frame_cfg<Q>::EPT, CAP = frame_cfg<Q>::CAP, RCAP = frame_cfg<Q>::RCAP;
     __shared__ double sb[CAP * Q];
     __shared__ double sA[RCAP * Q];
@@ -743,6 +757,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     // overlaps them.
     const int tid = threadIdx.x;
     const int stop = P->stop;
+    const int exact = P->exact;
 #if SBMBP_XCD_REMAP
     // Workgroup i is dispatched to XCD i % 8. The grid is padded to 8 * per workgroups (xcd_grid) and XCD x takes the
     // contiguous segments [x * per, (x+1) * per): its L2 then sees one stretch of rows, messages and marginals instead of
@@ -829,13 +844,18 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
         const int le = j * FTPB + tid;
         if (le < ne) {
             double bo[Q], inc[Q], b[Q];
-            edge_field<Q, false>(P, mo[j], 0.0, bo);  // what l saw of i's message at sweep t-1
-            double tot = 0.0;
+            if (first_from_psi) {  // uniform
 #pragma unroll
-            for (int s = 0; s < Q; ++s) { inc[s] = pl[j][s] / bo[s]; tot += inc[s]; }
-            const double inv = 1.0 / tot;
+                for (int s = 0; s < Q; ++s) inc[s] = pl[j][s];
+            } else {
+                edge_field<Q, false>(P, mo[j], 0.0, bo);  // what l saw of i's message at sweep t-1
+                double tot = 0.0;
 #pragma unroll
-            for (int s = 0; s < Q; ++s) inc[s] *= inv;  // m^t_{l->i}
+                for (int s = 0; s < Q; ++s) { inc[s] = pl[j][s] / bo[s]; tot += inc[s]; }
+                const double inv = 1.0 / tot;
+#pragma unroll
+                for (int s = 0; s < Q; ++s) inc[s] *= inv;  // m^t_{l->i}
+            }
             edge_field<Q, false>(P, inc, 0.0, b);
             store_vec<Q>(&sb[le * Q], b);
         }
@@ -941,7 +961,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
             for (int q = 0; q < Q; ++q) { cav[q] = A[q] / b[q]; tot += cav[q]; }
             const double inv = 1.0 / tot;
             double ref[Q];
-            if (Mcmp != nullptr) {  // uniform
+            if (exact) {  // uniform
                 load_msg<Q>(Mcmp, size_t(e0 + le), ref);
             } else {
 #pragma unroll
@@ -965,8 +985,9 @@ k_sweep_psi_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict
                 const double *__restrict__ psi_old, double *__restrict__ psi_new, const uint32_t *__restrict__ hub_row,
                 const uint32_t *__restrict__ hub_blk, const dev_params *__restrict__ P, int dc,
                 double *__restrict__ partials, const int32_t *__restrict__ clamp, shard_io io,
-                const double *__restrict__ Mcmp) {
+                const double *__restrict__ Mcmp, int first_from_psi) {
     if (P->stop) return;
+    const int exact = P->exact;
     __shared__ double sAq[BLOCK * Q];
     __shared__ int sEq[BLOCK * Q];
     __shared__ double sred[4 * (Q + 1)];
@@ -999,13 +1020,18 @@ k_sweep_psi_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict
         if (io.halo_stage != nullptr && l >= io.n_own) load_halo_row<Q>(io, l - io.n_own, pl);
         else load_vec<Q>(psi_old + size_t(l) * Q, pl);
         load_msg<Q>(Mio, size_t(e0 + le), mo);
-        edge_field<Q, false>(P, mo, 0.0, bo);
-        double tot = 0.0;
+        if (first_from_psi) {  // uniform
 #pragma unroll
-        for (int s = 0; s < Q; ++s) { inc[s] = pl[s] / bo[s]; tot += inc[s]; }
-        const double inv = 1.0 / tot;
+            for (int s = 0; s < Q; ++s) inc[s] = pl[s];
+        } else {
+            edge_field<Q, false>(P, mo, 0.0, bo);
+            double tot = 0.0;
 #pragma unroll
-        for (int s = 0; s < Q; ++s) inc[s] *= inv;
+            for (int s = 0; s < Q; ++s) { inc[s] = pl[s] / bo[s]; tot += inc[s]; }
+            const double inv = 1.0 / tot;
+#pragma unroll
+            for (int s = 0; s < Q; ++s) inc[s] *= inv;
+        }
         edge_field<Q, false>(P, inc, 0.0, b);
     };
     for (uint32_t le = tid; le < d; le += BLOCK) {
@@ -1032,7 +1058,7 @@ k_sweep_psi_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict
 #pragma unroll
         for (int q = 0; q < Q; ++q) { cav[q] = A[q] / b[q]; ct += cav[q]; }
         const double ci = 1.0 / ct;
-        if (Mcmp != nullptr) load_msg<Q>(Mcmp, size_t(e0 + le), mo);  // exact 1-step difference instead of the 2-step hint
+        if (exact) load_msg<Q>(Mcmp, size_t(e0 + le), mo);  // exact 1-step difference instead of the 2-step hint
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             out[q] = cav[q] * ci;
@@ -1202,7 +1228,7 @@ k_psi_sum(const uint32_t *__restrict__ row_ptr, const double *__restrict__ psi, 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLOCK)
 k_finalize(const double *__restrict__ partials, uint32_t n_part, int Q, int mode, dev_params *__restrict__ P,
-           double *__restrict__ diff_hist, uint32_t hist_cap) {
+           double *__restrict__ diff_hist, uint32_t hist_cap, int md_exact /* the sweep reported 1-step differences by nature */) {
     if (mode == 0 && P->stop) return;
     __shared__ double sacc[BLOCK * (QMAX + 1)];
     const int tid = threadIdx.x;
@@ -1243,7 +1269,14 @@ k_finalize(const double *__restrict__ partials, uint32_t n_part, int Q, int mode
             P->maxdiff = md;
             const int it = P->sweep_idx;
             if (diff_hist != nullptr && uint32_t(it) < hist_cap) diff_hist[it] = md;
-            if (md < P->crit && P->conv_iter < 0) { P->conv_iter = it; P->stop = 1; }
+            const bool is_hint = P->hinted && !P->exact && !md_exact;
+            P->last_exact = is_hint ? 0 : 1;
+            if (is_hint) {  // a 2-step hint: it can only arm the exact criterion
+                if (md < HINT_SCALE * P->crit) P->exact = 1;
+            } else if (md < P->crit && P->conv_iter < 0) {
+                P->conv_iter = it;
+                P->stop = 1;
+            }
             P->sweep_idx = it + 1;
         }
     }
@@ -1829,6 +1862,21 @@ k_init_random(double *__restrict__ v, uint64_t n_vec, int Q, int ncomp, uint64_t
         encode_msg_rt(t, Q, w);
         for (int q = 0; q < ncomp; ++q) v[i * ncomp + q] = w[q];
     }
+}
+
+// device initialisation: every out-message of a row starts as the row's (random) marginal, in both message buffers.
+// That state is consistent for the marginal-gather sweep without an explicit first sweep: the message l receives from i
+// IS psi_i, which is what the first sweep gathers (k_sweep_psi: first_from_psi).
+__global__ void __launch_bounds__(BLOCK)
+k_init_msgs_from_psi(const uint32_t *__restrict__ row_ptr, const double *__restrict__ psi, uint32_t n_rows, int Q,
+                     double *__restrict__ Ma, double *__restrict__ Mb) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_rows) return;
+    double v[QMAX], w[QMAX];
+    for (int q = 0; q < Q; ++q) v[q] = psi[size_t(i) * Q + q];
+    encode_msg_rt(v, Q, w);
+    for (uint32_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k)
+        for (int q = 0; q < Q - 1; ++q) { Ma[size_t(k) * (Q - 1) + q] = w[q]; Mb[size_t(k) * (Q - 1) + q] = w[q]; }
 }
 
 // host layout (Q components per message, sbmbp_set_state / sbmbp_get_state) <-> message records (Q-1 words)

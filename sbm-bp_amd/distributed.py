@@ -21,7 +21,8 @@ import numpy as np
 
 from sbm_bp_amd.plan import ShardPlan, block_cyclic_layout, busiest_link_rows, partition_rows, permute_csr
 
-HINT_SCALE = 8.0  # same rule as run_sweeps in csrc/engine.hip
+RED_GATHER_OFFSET = 32  # SBMBP_RED_GATHER_OFFSET (include/sbmbp.h): gathered rows start behind the shard's own red[0..Q]
+LEARN_FIELD_MIX, LEARN_SNAP = 0.3, 1.0  # defaults of sbmbp_set_learning_schedule (EM loop rules)
 EXACT_NONEDGE_MAX = 32768  # up to this many vertices the non-edge term is the exact all-pairs sum (engine.hip: nonedge_terms)
 
 
@@ -34,7 +35,7 @@ class ShardDesc(C.Structure):
 
 class ConvState(C.Structure):
     _fields_ = [("maxdiff", C.c_double), ("conv_iter", C.c_int), ("sweep_idx", C.c_int), ("stop", C.c_int),
-                ("reserved", C.c_int)]
+                ("last_exact", C.c_int)]
 
 
 class HipShardBackend:
@@ -196,11 +197,8 @@ class HipShardBackend:
     def commit(self, n):
         self._check(self._lib.sbmbp_shard_commit(self._h, n))
 
-    def rearm(self, armed):
-        self._check(self._lib.sbmbp_shard_rearm(self._h, armed))
-
-    def set_exact(self, on):
-        self._check(self._lib.sbmbp_shard_set_exact(self._h, int(bool(on))))
+    def set_schedule(self, field_mix, check_every=1):
+        self._check(self._lib.sbmbp_set_schedule(self._h, field_mix, check_every))
 
     def get_state(self):
         from sbm_bp_amd.capi import c_dp
@@ -445,11 +443,14 @@ class ShardedBP:
             self.comm.all_reduce([sh.red[n_sum:n_sum + n_max] for sh in self.shards], "max")
 
     def _gather_red(self):
-        """every shard's red[0..Q] (Q field sums + hint) -> all shards, at red[16 + r*(Q+1)]: ONE collective
-        per sweep; k_finalize folds the rows (sum / max) in rank order, identically on every shard"""
+        """every shard's red[0..Q] (Q field sums + max difference) -> all shards, at red[RED_GATHER_OFFSET + r*(Q+1)]: ONE
+        collective per sweep; k_finalize folds the rows (sum / max) in rank order, identically on every shard. The
+        gathered rows start behind the largest possible input (Q = 16: 17 values), so input and output never overlap."""
         n = self.Q + 1
         w = self.comm.world
-        self.comm.all_gather([sh.red[16:16 + w * n] for sh in self.shards], [sh.red[:n] for sh in self.shards])
+        o = RED_GATHER_OFFSET
+        assert n <= o
+        self.comm.all_gather([sh.red[o:o + w * n] for sh in self.shards], [sh.red[:n] for sh in self.shards])
 
     def _queue_sweep(self, j):
         """sweep j reads a table whose halo is already in place (shipped during sweep j-1 or by _begin);
@@ -527,8 +528,9 @@ class ShardedBP:
         return float(self.shards[0].red[0].item())
 
     def _run(self, crit, max_sweeps, check_every, want_diff):
-        armed = HINT_SCALE * crit if crit > 0 else -1.0
-        self._begin(armed)
+        """the convergence decision runs on the device (2-step hints arm the exact 1-step criterion, which sets the stop
+        flag: kernels.h dev_params); identical on every shard because k_finalize folds the same gathered rows"""
+        self._begin(crit if crit > 0 else -1.0)
         done, st = 0, None
         while done < max_sweeps:
             batch = min(check_every, max_sweeps - done)
@@ -542,33 +544,10 @@ class ShardedBP:
         executed = st.sweep_idx if st is not None else 0
         for sh in self.shards:
             sh.commit(executed)
-        niter, exact = -1, None
-        if executed and (want_diff or (st.stop and crit > 0)):
+        niter = st.conv_iter if st is not None else -1
+        exact = st.maxdiff if st is not None else None
+        if executed and want_diff and not st.last_exact:  # the last sweep reported a 2-step hint
             exact = self._exact_diff()
-        if st is not None and st.stop and crit > 0:
-            if exact < crit:
-                niter = st.conv_iter
-            else:
-                # the hint fired early: from here the chunks report the exact 1-step difference themselves and the stop flag
-                # is armed at the real criterion, so the run goes on in batches (no all-reduce + host check per sweep)
-                for sh in self.shards:
-                    sh.set_exact(True)
-                    sh.rearm(crit)
-                while executed < max_sweeps:
-                    batch = min(check_every, max_sweeps - executed)
-                    for b in range(batch):
-                        self._queue_sweep(b)
-                    st = [sh.poll() for sh in self.shards][0]
-                    ran = st.sweep_idx - executed
-                    for sh in self.shards:
-                        sh.commit(ran)
-                    executed += ran
-                    exact = st.maxdiff
-                    if st.stop:
-                        niter = st.conv_iter
-                        break
-                for sh in self.shards:
-                    sh.set_exact(False)
         self.total_sweeps += executed
         return niter, exact
 
@@ -684,6 +663,15 @@ class ShardedBP:
         lr = float(np.float32(learning_rate))
         fold, fdiff, steps, status, sweeps0 = 0.0, 1.0, 0, 0, self.total_sweeps
         N, Q = self.N_global, self.Q
+        for sh in self.shards:  # field relaxation inside the EM loop (sbmbp_set_learning_schedule)
+            sh.set_schedule(LEARN_FIELD_MIX)
+        try:
+            return self._learning_loop(crit, lr, fold, fdiff, steps, status, sweeps0, N, Q, learning_max_time, dumping_rate)
+        finally:
+            for sh in self.shards:
+                sh.set_schedule(1.0)
+
+    def _learning_loop(self, crit, lr, fold, fdiff, steps, status, sweeps0, N, Q, learning_max_time, dumping_rate):
         for _ in range(int(learning_max_time)):
             if fdiff < float(crit):
                 crit = np.float32(float(crit) * 0.1)
@@ -699,8 +687,9 @@ class ShardedBP:
                 break
             na = self.na.astype(np.int64)
             rest = N
+            snap = min(LEARN_SNAP * N * float(crit), 0.01)
             for i in range(Q - 1):
-                na[i] = int(lr * na_e[i] + (1.0 - lr) * na[i])
+                na[i] = int(lr * na_e[i] + (1.0 - lr) * na[i] + snap)
                 rest -= na[i]
             na[Q - 1] = rest
             cab = lr * cab_e + (1.0 - lr) * self.cab

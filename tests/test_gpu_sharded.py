@@ -216,7 +216,7 @@ def test_sharded_learning_matches_single_engine_and_reference(S, orc):
 @pytest.mark.parametrize("name,world", [("q4_tight_seed0", 3)])
 def test_three_processes_share_one_gpu(orc, tmp_path, name, world):
     """the multi-PROCESS driver with the HIP shard kernels: one shard per process, every process on cuda:0, the
-    collectives over gloo through host memory (RCCL refuses two ranks on one device, tools/nccl_dup_test.py).
+    collectives over gloo through host memory (RCCL refuses two ranks on one device, tools/probe_nccl_dup.py).
     Same calls, same order, same chunking as the RCCL path; result = the in-process run."""
     import os
     import subprocess
