@@ -248,8 +248,11 @@ def main():
             bp.reinit_messages_device(tc, 1234)
             bp.expand_bp_params(state)
     else:
-        from sbm_bp_amd.distributed import ShardedBP, HostStagedComm
-        runner = ShardedBP.synthetic(N, Q, c, eps, gseed, dc=dc, seed=1234, comm=HostStagedComm() if rehearsal else None)
+        # the ranks join the library's own RCCL communicators (torch.distributed only carried the id and, below, the
+        # barriers around the timed regions); rehearsal: the same C++ driver with gloo between the processes
+        from sbm_bp_amd.distributed import Comm, ShardedBP
+        comm = Comm.callbacks_from_torch() if rehearsal else Comm.rccl_from_torch(local_rank)
+        runner = ShardedBP.synthetic(N, Q, c, eps, gseed, dc=dc, seed=1234, comm=comm, device=local_rank)
         E2_total = runner.E2_global
 
         def reinit():
@@ -323,11 +326,12 @@ def main():
         if traffic_note:
             out["roofline"]["traffic_source" if traffic is not None else "traffic_stale"] = traffic_note
         if sharded:  # what rank 0 ships per sweep: the numbers needed to read a multi-GPU result
-            out["n_ranks_seen"] = dist.get_world_size()
-            p0, sh0 = runner.plans[0], runner.shards[0]
-            per_peer = p0.send_counts.astype(float) * sh0.ncomp * 8 / 1e6
-            out["config"]["exchange"] = {"chunks": int(p0.n_chunks), "payload_components": int(sh0.ncomp),
-                                         "halo_rows": int(p0.n_halo), "sent_MB_per_sweep": round(float(per_peer.sum()), 2),
+            out["n_ranks_seen"] = runner.comm.world  # ranks of the communicator the sweeps ran on
+            info = runner.info
+            per_peer = runner.peer_rows()[0].astype(float) * info.halo_components * 8 / 1e6
+            out["config"]["exchange"] = {"transport": runner.comm.transport, "chunks": int(info.n_chunks),
+                                         "payload_components": int(info.halo_components), "halo_rows": int(info.n_halo),
+                                         "sent_MB_per_sweep": round(float(per_peer.sum()), 2),
                                          "busiest_peer_MB_per_sweep": round(float(per_peer.max()) if len(per_peer) else 0.0, 2)}
             if phases:  # rank 0's stream: chunk kernels / fold + all-gather + finalize / wait for exchanges still in flight
                 out["config"]["exchange"]["rank0_ms_per_sweep"] = {k: round(v, 4) for k, v in phases.items() if k != "sweeps"}
@@ -340,33 +344,39 @@ def main():
             out["cpu_baseline"] = cpu_baseline(Q, c, eps)  # plain planted partition of the same Q, c (also for C4)
         print(json.dumps(out), flush=True)
     if sharded:
+        runner.close()
         dist.barrier()
         dist.destroy_process_group()
 
 
 def dry_run(args, rank, world, N, Q, c, eps, dc, gseed):
-    """no GPU: every rank builds its shard plan of a small graph of the workload's family and the ranks cross-check what
-    they will send each other (rank r's send count to p must be rank p's receive count from r)"""
+    """no GPU: every rank builds its shard plan (csrc/dist.hip, host code) of a small graph of the workload's family and the
+    ranks cross-check what they will send each other (rank r's send count to p must be rank p's receive count from r)"""
+    import ctypes as C
     import numpy as np
     import torch
     import torch.distributed as dist
     import sbm_bp_amd as S
     from sbm_bp_amd import synth
-    from sbm_bp_amd.plan import ShardPlan, partition_rows
+    from sbm_bp_amd.capi import DistInfo, c_u64p, check
     n = min(N, 200_000)
     pairs, _, _ = synth.planted_partition(n, Q, c, eps, gseed)
-    row_ptr, nbr, _ = S.Graph.from_edges(pairs, n).csr()
-    plan = ShardPlan(row_ptr, nbr, partition_rows(row_ptr, world), rank, 2)
+    g = S.Graph.from_edges(pairs, n)
+    info = DistInfo()
+    sc, rc, mc = (np.zeros(world, dtype=np.uint64) for _ in range(3))
+    check(S.load_library().sbmbp_plan_summary(g._h, world, rank, 2, C.byref(info), sc.ctypes.data_as(c_u64p), rc.ctypes.data_as(c_u64p),
+                                              mc.ctypes.data_as(c_u64p)))
     ok = True
     if world > 1:
-        mine = torch.tensor(np.concatenate([plan.send_counts, plan.recv_counts]), dtype=torch.int64)
+        mine = torch.tensor(np.concatenate([sc, rc, mc]).astype(np.int64))
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
-        for p in range(world):
-            ok = ok and int(allv[p][world + rank]) == int(plan.send_counts[p])  # what p expects from me
+        for p in range(world):  # what p expects from me (marginal rows and cut-edge records)
+            ok = ok and int(allv[p][world + rank]) == int(sc[p]) and int(allv[p][2 * world + rank]) == int(mc[p])
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
-                          "plans_consistent": bool(ok), "sample_N": n, "halo_rows_rank0": int(plan.n_halo)}), flush=True)
+                          "plans_consistent": bool(ok), "sample_N": n, "halo_rows_rank0": int(info.n_halo),
+                          "cut_edge_records_rank0": int(info.n_halo_msgs)}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

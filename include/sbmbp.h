@@ -40,6 +40,7 @@ extern "C" {
 #define SBMBP_ERR_IO (-5)          /* file could not be read */
 #define SBMBP_ERR_UNSUPPORTED (-6) /* e.g. Q above SBMBP_MAX_Q */
 #define SBMBP_ERR_NOMEM (-7)
+#define SBMBP_ERR_COMM (-8)        /* a collective (RCCL or the caller's transport) failed */
 
 #define SBMBP_MAX_Q 16 /* label count handled by the templated kernels */
 
@@ -216,6 +217,11 @@ typedef struct sbmbp_shard_desc {
     void *red_buf;              /* device, >= 8192 doubles: reduction hand-off buffer */
     uint32_t n_chunks;          /* row chunks for overlapping the halo exchange with the sweep (0 or 1 = none) */
     const uint32_t *chunk_row;  /* host [n_chunks+1] local row boundaries, chunk_row[0] = 0, last = n_own */
+    /* optional: what the message-gather sweep needs on a shard (any damping, clamped rows, deg_corr_flag 2, zeros in cab) */
+    const uint32_t *rev_local;  /* host [n_edges] or NULL: record holding the reverse message of every edge: < n_edges for an own
+                                   neighbour, n_edges + r for the r-th record received from the peers */
+    uint64_t n_halo_msgs;       /* records received from the peers, kept behind the own records of each message buffer */
+    const uint32_t *table_deg;  /* host [n_own + n_halo] or NULL: degree of every vertex of the marginal table (deg_corr_flag 2) */
 } sbmbp_shard_desc;
 
 typedef struct sbmbp_conv_state {
@@ -230,7 +236,25 @@ int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *desc, uint3
 /* start a run of sweeps: uploads parameters and the convergence criterion (< 0: never converges). The sweeps report
  * 2-step hints until one falls below 8 * crit; from then on they report the reference's 1-step difference and the
  * device-side stop flag works on it (all on the device: no host round trip) */
-int sbmbp_shard_begin(sbmbp_engine_t *e, double crit);
+int sbmbp_shard_begin(sbmbp_engine_t *e, double crit, int hinted /* 1: the run uses the marginal-gather sweep */);
+/* planted configuration and true labels of the owned rows (init_messages, belief_propagation.cpp:106-108, 132-216);
+ * any_clamp_global: some vertex of the WHOLE graph is clamped (every shard must take the same kernel variants) */
+int sbmbp_shard_set_labels(sbmbp_engine_t *e, const int32_t *conf_local, const uint32_t *true_conf_local, uint32_t flag,
+                           int conditional, int any_clamp_global);
+/* 0: every cab entry > 0; 1: clamped rows exist; 2: they hold the one-hot state of init flag 1/3; 3: the state is the device
+ * initialisation (message = sender's marginal); 4: the shard has a reverse index */
+int sbmbp_shard_query(sbmbp_engine_t *e, int what);
+/* message-gather form of sweep j over all owned rows (k_sweep: belief_propagation.cpp:991-1071 as the single engine runs
+ * it). The incoming messages of the cut edges are the records behind the own ones of the buffer sweep j reads:
+ * sbmbp_shard_msg_halo(e, j) is where the caller receives them (n_halo_msgs records of Q-1 doubles, in rev_local's
+ * numbering) and sbmbp_shard_pack_msgs gathers the records it has to send from the same buffer. */
+int sbmbp_shard_sweep_explicit(sbmbp_engine_t *e, uint32_t j, double damping);
+void *sbmbp_shard_msg_halo(sbmbp_engine_t *e, uint32_t j);
+int sbmbp_shard_pack_msgs(sbmbp_engine_t *e, uint32_t j, const uint32_t *d_edge_idx, uint32_t n, double *d_out);
+/* where the reductions below take the incoming messages from: 0 = materialised from the marginal table (needs marginals
+ * consistent with the messages and cab > 0), 1 = gathered through rev_local (the caller received the halo records of the
+ * current buffer, sbmbp_shard_msg_halo(e, 0)) */
+int sbmbp_shard_set_incoming(sbmbp_engine_t *e, int source);
 /* gather rows idx[0..n) of the marginal table that sweep j READS into out (device pointers), ncomp
  * components per row: Q, or Q-1 to ship the marginals without their last component (they sum to 1) */
 int sbmbp_shard_pack(sbmbp_engine_t *e, uint32_t j, const uint32_t *d_idx, uint32_t n, double *d_out, uint32_t ncomp);
@@ -259,7 +283,7 @@ int sbmbp_shard_sweep_fold(sbmbp_engine_t *e);
 /* consume the reduction values: n_rows rows of (Q+1) doubles starting at red + SBMBP_RED_GATHER_OFFSET (the caller
  * all-gathers every shard's red[0..Q] there; n_rows = number of shards). Rows are folded in order —
  * sums for the Q field entries, max for the hint. mode 0 after a sweep, 1 field initialisation */
-int sbmbp_shard_finalize(sbmbp_engine_t *e, int mode, uint32_t n_rows);
+int sbmbp_shard_finalize(sbmbp_engine_t *e, int mode, uint32_t n_rows, int md_exact /* the sweep was a message-gather sweep */);
 /* red[0] = max |m_a - m_b| over the two message buffers of this shard (exact 1-step criterion) */
 int sbmbp_shard_msgdiff_partial(sbmbp_engine_t *e);
 /* red[0..2Q+Q*Q) = na_expect, nna_expect, confusion sums over the owned rows (current marginals) */
@@ -281,8 +305,97 @@ int sbmbp_shard_em_finish(sbmbp_engine_t *e, double *na_expect, double *nna_expe
 
 /* wait for the stream and read the convergence state */
 int sbmbp_shard_poll(sbmbp_engine_t *e, sbmbp_conv_state *out);
+/* the same without idling the GPU: record queues a copy of the state into page-locked slot 0/1 behind the work queued so far,
+ * wait blocks until that copy has landed (the caller may queue the next batch in between) */
+int sbmbp_shard_state_record(sbmbp_engine_t *e, int slot);
+int sbmbp_shard_state_wait(sbmbp_engine_t *e, int slot, sbmbp_conv_state *out);
 /* after a poll: `executed` sweeps of the queued batch really ran; flips the buffer parities */
 int sbmbp_shard_commit(sbmbp_engine_t *e, uint32_t executed);
+/* ---------------------------------------------------------------------------------------------
+ * Multi-GPU: communicators and the per-rank driver (csrc/dist.hip). No reference counterpart; this is what replaces the
+ * call sequence of main.cpp:318-365 when the graph is sharded over the GPUs of one node. One sbmbp_dist_t = one rank = one
+ * GPU = one host thread. The ranks of a run are processes (one per GPU; they share a communicator id) or threads of one
+ * process (bin/bp --gpus N). All ranks hold the whole host graph and make the same calls in the same order; every
+ * convergence decision is taken on the device from identical all-gathered values, so no rank ever needs to be told.
+ * Per sweep: the boundary marginals travel by grouped ncclSend/ncclRecv over xGMI while the next row chunk is swept, then
+ * ONE all-gather of Q+1 doubles per rank (field sums + message difference). The message-gather sweep (damping, clamped
+ * rows, deg_corr_flag 2, zeros in cab, first sweep after a state or parameter change) ships the messages of the cut edges
+ * instead. Results are partition invariant up to the summation order of the Q field sums.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct sbmbp_comm sbmbp_comm_t;
+typedef struct sbmbp_dist sbmbp_dist_t;
+#define SBMBP_COMM_ID_BYTES 256
+/* RCCL: rank 0 draws an id (two ncclUniqueId: one communicator for the halo exchange, one for the reductions) and hands it
+ * to the other ranks by whatever means the launcher has (torch.distributed in bench.py, shared memory between threads) */
+int sbmbp_comm_unique_id(void *id_out /* SBMBP_COMM_ID_BYTES */);
+int sbmbp_comm_init_rank(sbmbp_comm_t **out, const void *id, int n_ranks, int rank, int device);
+/* the ranks are n threads of this process (possibly sharing one GPU, where RCCL refuses duplicate devices): fills out[0..n),
+ * one handle per rank thread. Tests and rehearsals. */
+int sbmbp_comm_init_local(sbmbp_comm_t **out, int n_ranks);
+/* the ranks are processes with the caller's own transport between them (e.g. gloo): buffers are staged through host memory.
+ * Rows for / from peer p are contiguous, in rank order; every function returns 0 on success. Rehearsals on a 1-GPU box. */
+typedef struct sbmbp_comm_callbacks {
+    void *user;
+    int (*exchange)(void *user, const double *send, const uint64_t *send_rows, double *recv, const uint64_t *recv_rows, int row_doubles);
+    int (*allgather)(void *user, const double *in, uint64_t n, double *out /* n_ranks * n */);
+    int (*allreduce)(void *user, double *buf, uint64_t n, int op /* 0 sum, 1 max */);
+} sbmbp_comm_callbacks;
+int sbmbp_comm_init_callbacks(sbmbp_comm_t **out, int n_ranks, int rank, const sbmbp_comm_callbacks *cb);
+void sbmbp_comm_destroy(sbmbp_comm_t *c);
+int sbmbp_comm_rank(const sbmbp_comm_t *c);
+int sbmbp_comm_size(const sbmbp_comm_t *c);
+const char *sbmbp_comm_transport(const sbmbp_comm_t *c); /* "rccl" | "local" | "callbacks" */
+
+typedef struct sbmbp_dist_info_t {
+    int rank, world;
+    uint32_t n_global, row0, n_own, n_halo, n_chunks, halo_components;
+    uint64_t n_edges, e2_global, n_halo_msgs;
+    uint64_t sent_rows_per_sweep, busiest_peer_rows; /* marginal rows shipped per marginal-gather sweep */
+} sbmbp_dist_info_t;
+
+/* the shard of rank sbmbp_comm_rank(comm): plan (row range balanced on sum(deg+2), halo, send lists, cut edges), device
+ * buffers, shard engine. g is borrowed and must outlive the engine (as the adjacency must in the reference,
+ * belief_propagation.h:27). n_chunks = 0: default (4, or SBMBP_SHARD_CHUNKS; 1 for a single rank). */
+int sbmbp_dist_create(sbmbp_dist_t **out, sbmbp_comm_t *comm, const sbmbp_graph_t *g, uint32_t Q, uint32_t deg_corr_flag, int device,
+                      uint32_t n_chunks);
+void sbmbp_dist_destroy(sbmbp_dist_t *d);
+int sbmbp_dist_info(const sbmbp_dist_t *d, sbmbp_dist_info_t *out);
+int sbmbp_dist_peer_rows(const sbmbp_dist_t *d, uint64_t *send_rows /* [world] or NULL */, uint64_t *recv_rows);
+/* the calls below mirror the single-engine ones above (same reference citations); conf / true_conf are the GLOBAL vectors */
+int sbmbp_dist_init_messages(sbmbp_dist_t *d, uint32_t flag, const int32_t *conf, const uint32_t *true_conf, uint32_t seed,
+                             int conditional);
+int sbmbp_dist_init_messages_device(sbmbp_dist_t *d, uint64_t seed, const uint32_t *true_conf);
+int sbmbp_dist_set_state(sbmbp_dist_t *d, const double *psi_own /* n_own*Q */, const double *msg_own /* n_edges*Q */);
+int sbmbp_dist_get_state(sbmbp_dist_t *d, double *psi_own, double *msg_own);
+int sbmbp_dist_gather_marginals(sbmbp_dist_t *d, double *psi_all /* n_global*Q, filled on every rank */);
+int sbmbp_dist_set_params(sbmbp_dist_t *d, const double *cab, const uint32_t *na, double beta);
+int sbmbp_dist_get_params(sbmbp_dist_t *d, double *cab, uint32_t *na);
+int sbmbp_dist_set_schedule(sbmbp_dist_t *d, double field_mix, uint32_t check_every);
+int sbmbp_dist_set_learning_schedule(sbmbp_dist_t *d, double field_mix, double snap);
+int sbmbp_dist_set_gather_mode(sbmbp_dist_t *d, int mode);
+int sbmbp_dist_converge(sbmbp_dist_t *d, double crit, uint32_t max_sweeps, double damping, int *niter, double *last_maxdiff);
+int sbmbp_dist_sweep(sbmbp_dist_t *d, double damping, uint32_t n_sweeps, double *last_maxdiff);
+int sbmbp_dist_free_energy(sbmbp_dist_t *d, double *f, double *parts);
+int sbmbp_dist_entropy(sbmbp_dist_t *d, double *entropy, double *parts);
+int sbmbp_dist_em_expectations(sbmbp_dist_t *d, double *na_expect, double *nna_expect, double *cab_expect);
+int sbmbp_dist_confusion(sbmbp_dist_t *d, double *C);
+int sbmbp_dist_overlap(sbmbp_dist_t *d, double *overlap);
+int sbmbp_dist_inference(sbmbp_dist_t *d, float conv_crit, uint32_t time_conv, float dumping_rate, sbmbp_infer_result *out);
+int sbmbp_dist_learning(sbmbp_dist_t *d, float learning_conv_crit, uint32_t learning_max_time, float learning_rate, float dumping_rate,
+                        sbmbp_learn_result *out);
+int sbmbp_dist_get_stats(sbmbp_dist_t *d, sbmbp_stats *out); /* kernel times and bytes are this rank's; sweeps are the run's */
+int sbmbp_dist_reset_stats(sbmbp_dist_t *d);
+int sbmbp_dist_set_timing(sbmbp_dist_t *d, int on);
+/* while timing is on: mean ms per marginal-gather sweep on this rank's compute stream spent in {chunk kernels (with whatever
+ * exchange time they could not hide), fold + all-gather + finalize, waiting for exchanges still in flight} */
+int sbmbp_dist_phase_times(sbmbp_dist_t *d, double ms_per_sweep[3], uint64_t *n_sweeps);
+/* the plan without a device (tests, dry runs) */
+int sbmbp_plan_summary(const sbmbp_graph_t *g, int world, int rank, uint32_t n_chunks, sbmbp_dist_info_t *info, uint64_t *send_rows,
+                       uint64_t *recv_rows, uint64_t *msg_rows);
+int sbmbp_plan_arrays(const sbmbp_graph_t *g, int world, int rank, uint32_t n_chunks, uint32_t *nbr_local, uint32_t *halo_global,
+                      uint32_t *chunk_row, uint64_t *send_counts_cp, uint64_t *recv_counts_cp, uint32_t *send_idx_chunked,
+                      uint32_t *snd_ptr, uint32_t *snd_slot, uint32_t *rev_local, uint32_t *msg_send_edge);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,12 +17,12 @@ def lib_path():
 
 def build_variant(name, defines):
     """compile a tuning variant csrc/variants/libsbmbp_<name>.so with extra -D flags"""
-    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "host_graph.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "dist.hip", "host_graph.cpp")]
     vdir = os.path.join(CSRC, "variants")
     os.makedirs(vdir, exist_ok=True)
     out = os.path.join(vdir, "libsbmbp_%s.so" % name)
     subprocess.check_call([_hipcc(), "-std=c++14", "-O3", "--offload-arch=" + ARCH, "-fPIC", "-shared", "-pthread", "-o", out] +
-                          ["-D" + d for d in defines] + srcs)
+                          ["-D" + d for d in defines] + srcs + ["-lrccl"])
     return out
 
 
@@ -42,11 +42,11 @@ def _hipcc():
 
 
 def build_lib(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "host_graph.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "dist.hip", "host_graph.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("kernels.h", "host_graph.h")] + [os.path.join(ROOT, "include", "sbmbp.h")]
     out = os.path.join(CSRC, "libsbmbp_hip.so")
     if force or _newer(out, deps):
-        cmd = [_hipcc(), "-std=c++14", "-O3", "--offload-arch=" + ARCH, "-fPIC", "-shared", "-pthread", "-o", out] + srcs
+        cmd = [_hipcc(), "-std=c++14", "-O3", "--offload-arch=" + ARCH, "-fPIC", "-shared", "-pthread", "-o", out] + srcs + ["-lrccl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -53,6 +53,9 @@ struct sbmbp_engine {
     std::vector<uint32_t> chunk_blk, chunk_hub;  // per row chunk: first segment / first hub row (n_chunks+1 entries)
     // graph + work decomposition in HBM
     uint32_t *d_row_ptr = nullptr, *d_rev = nullptr, *d_nbr = nullptr, *d_src = nullptr;
+    uint32_t *d_deg = nullptr;     // dc 2: degree of every row of the marginal table (own rows, then halo vertices on a shard)
+    uint64_t n_halo_msgs = 0;      // shards: message records received from peers, kept behind the own records (rev points there)
+    int incoming_src = 0;          // shards, reductions: 0 = incoming messages materialised from the marginals, 1 = gathered through rev
     uint32_t *d_blk_row = nullptr, *d_blk_e0 = nullptr, *d_hub_row = nullptr, *d_hub_blk = nullptr, *d_true = nullptr;
     int32_t *d_clamp = nullptr;
     uint32_t n_blk = 0, n_hub = 0;
@@ -242,11 +245,11 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form, bool f
         } else if (e->n_hub) {
             if (e->dc == 2) {
                 DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, hs,
-                                                    e->d_row_ptr, e->d_rev, e->d_nbr, Mold, Mnew, psi_old, psi_new, clamp,
+                                                    e->d_row_ptr, e->d_rev, e->d_nbr, e->d_deg, Mold, Mnew, psi_old, psi_new, clamp,
                                                     e->d_hub_row, e->d_hub_blk, e->d_P, 1, damp, e->d_partials));
             } else {
                 DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, false>), dim3(e->n_hub), dim3(BLOCK), 0, hs,
-                                                    e->d_row_ptr, e->d_rev, e->d_nbr, Mold, Mnew, psi_old, psi_new, clamp,
+                                                    e->d_row_ptr, e->d_rev, e->d_nbr, e->d_deg, Mold, Mnew, psi_old, psi_new, clamp,
                                                     e->d_hub_row, e->d_hub_blk, e->d_P, int(e->dc), damp, e->d_partials));
             }
         }
@@ -276,11 +279,11 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form, bool f
         }
     } else if (e->dc == 2) {
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, true>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
-                                            e->d_rev, e->d_nbr, Mold, Mnew, psi_old, psi_new, clamp, e->d_blk_row, e->d_blk_e0, e->d_P,
+                                            e->d_rev, e->d_nbr, e->d_deg, Mold, Mnew, psi_old, psi_new, clamp, e->d_blk_row, e->d_blk_e0, e->d_P,
                                             1, damp, e->d_partials));
     } else {
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, false>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
-                                            e->d_rev, e->d_nbr, Mold, Mnew, psi_old, psi_new, clamp, e->d_blk_row, e->d_blk_e0, e->d_P,
+                                            e->d_rev, e->d_nbr, e->d_deg, Mold, Mnew, psi_old, psi_new, clamp, e->d_blk_row, e->d_blk_e0, e->d_P,
                                             int(e->dc), damp, e->d_partials));
     }
     if (e->timing) HIPCHK(hipEventRecord(e1, e->stream));
@@ -450,21 +453,21 @@ int refresh_field(sbmbp_engine *e) {
 int site_edge_terms(sbmbp_engine *e, bool want_entropy, double out[4], double *d_out = nullptr) {
     CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (FE_NP + 1)));
     const double *M = e->d_M[e->cur];
-    const double *Min = e->sharded ? e->d_Min : nullptr;
+    const double *Min = (e->sharded && e->incoming_src == 0) ? e->d_Min : nullptr;
     if (e->dc == 2) {
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_frame<QQ, true>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
-                                            e->d_rev, e->d_nbr, M, Min, e->d_blk_row, e->d_P, 1, int(want_entropy), e->d_partials));
+                                            e->d_rev, e->d_nbr, e->d_deg, M, Min, e->d_blk_row, e->d_P, 1, int(want_entropy), e->d_partials));
         if (e->n_hub)
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
-                                                e->d_rev, e->d_nbr, M, Min, e->d_hub_row, e->d_hub_blk, e->d_P, 1,
+                                                e->d_rev, e->d_nbr, e->d_deg, M, Min, e->d_hub_row, e->d_hub_blk, e->d_P, 1,
                                                 int(want_entropy), e->d_partials));
     } else {
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_frame<QQ, false>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
-                                            e->d_rev, e->d_nbr, M, Min, e->d_blk_row, e->d_P, int(e->dc), int(want_entropy),
+                                            e->d_rev, e->d_nbr, e->d_deg, M, Min, e->d_blk_row, e->d_P, int(e->dc), int(want_entropy),
                                             e->d_partials));
         if (e->n_hub)
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_hub<QQ, false>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
-                                                e->d_rev, e->d_nbr, M, Min, e->d_hub_row, e->d_hub_blk, e->d_P, int(e->dc),
+                                                e->d_rev, e->d_nbr, e->d_deg, M, Min, e->d_hub_row, e->d_hub_blk, e->d_P, int(e->dc),
                                                 int(want_entropy), e->d_partials));
     }
     HIPCHK(hipGetLastError());
@@ -621,13 +624,13 @@ int em_expect(sbmbp_engine *e, double *na_e, double *nna_e, double *cab_e) {
     // k_em_edges reads cab/invN from the parameter block, which is in sync with the host mirror here:
     // sbmbp_set_params uploads, and inside learning the preceding converge uploaded.
     const double *M = e->d_M[e->cur];
-    const double *Min = e->sharded ? e->d_Min : nullptr;
+    const double *Min = (e->sharded && e->incoming_src == 0) ? e->d_Min : nullptr;
     if (e->dc == 2) {
         DISPATCH_Q(Q, hipLaunchKernelGGL((k_em_edges<QQ, true>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_rev,
-                                         e->d_nbr, e->d_src, M, Min, uint32_t(e->E2), e->d_P, e->d_partials));
+                                         e->d_nbr, e->d_deg, e->d_src, M, Min, uint32_t(e->E2), e->d_P, e->d_partials));
     } else {
         DISPATCH_Q(Q, hipLaunchKernelGGL((k_em_edges<QQ, false>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_rev,
-                                         e->d_nbr, e->d_src, M, Min, uint32_t(e->E2), e->d_P, e->d_partials));
+                                         e->d_nbr, e->d_deg, e->d_src, M, Min, uint32_t(e->E2), e->d_P, e->d_partials));
     }
     HIPCHK(hipGetLastError());
     std::vector<double> tri(T);
@@ -743,6 +746,7 @@ const char *sbmbp_strerror(int code) {
         case SBMBP_ERR_IO: return "I/O error";
         case SBMBP_ERR_UNSUPPORTED: return "unsupported configuration";
         case SBMBP_ERR_NOMEM: return "out of device memory";
+        case SBMBP_ERR_COMM: return "collective communication failed";
         default: return "unknown error";
     }
 }
@@ -890,6 +894,11 @@ int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint3
     if (dc == 2) {
         TRY(dev_alloc(e, &e->d_src, e->E2));
         hipLaunchKernelGGL(k_fill_src, dim3((e->N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->N, e->d_src);
+        std::vector<uint32_t> deg(e->N);
+        for (uint32_t i = 0; i < g->n; ++i) deg[i] = g->deg(i);
+        TRY(dev_alloc(e, &e->d_deg, e->N));
+        TRYHIP(hipMemcpyAsync(e->d_deg, deg.data(), size_t(e->N) * 4, hipMemcpyHostToDevice, e->stream));
+        TRYHIP(hipStreamSynchronize(e->stream));  // deg is a local
     }
     if (dc == 1) {  // sum over directed edges of log(d_i d_l) = 2 sum_i d_i log d_i
         double s = 0.0;
@@ -908,7 +917,7 @@ void sbmbp_destroy(sbmbp_engine_t *e) {
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->ext_psi) e->d_psi[0] = e->d_psi[1] = nullptr;  // caller-owned
-    void *ptrs[] = {e->d_row_ptr, e->d_rev, e->d_nbr, e->d_src, e->d_blk_row, e->d_blk_e0, e->d_hub_row, e->d_hub_blk, e->d_true,
+    void *ptrs[] = {e->d_deg, e->d_row_ptr, e->d_rev, e->d_nbr, e->d_src, e->d_blk_row, e->d_blk_e0, e->d_hub_row, e->d_hub_blk, e->d_true,
                     e->d_clamp, e->d_M[0], e->d_M[1], e->d_psi[0], e->d_psi[1], e->d_Min, e->d_snd_ptr, e->d_snd_slot, e->d_P, e->d_partials, e->d_small, e->d_hist, e->d_mats,
                     e->d_stage};
     for (void *p : ptrs) if (p) hipFree(p);
@@ -1307,7 +1316,12 @@ int sbmbp_set_timing(sbmbp_engine_t *e, int on) {
 int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *d, uint32_t Q, uint32_t dc, int device) {
     if (!out || !d || !d->row_ptr || (!d->nbr_local && d->n_edges) || !d->psi_buf0 || !d->psi_buf1 || !d->red_buf) return SBMBP_ERR_ARG;
     if (Q < 2 || Q > SBMBP_MAX_Q) { set_error("Q must be in [2, 16]"); return SBMBP_ERR_UNSUPPORTED; }
-    if (dc > 1) { set_error("sharded engines support deg_corr_flag 0 and 1"); return SBMBP_ERR_UNSUPPORTED; }
+    if (dc > 2) { set_error("deg_corr_flag must be 0, 1 or 2"); return SBMBP_ERR_ARG; }
+    if (dc == 2 && (!d->rev_local || !d->table_deg)) { set_error("a dc 2 shard needs rev_local and table_deg (it runs the message-gather sweep)"); return SBMBP_ERR_ARG; }
+    if (d->n_halo_msgs && !d->rev_local) { set_error("n_halo_msgs without rev_local"); return SBMBP_ERR_ARG; }
+    if (d->rev_local)
+        for (uint64_t k = 0; k < d->n_edges; ++k)
+            if (d->rev_local[k] >= d->n_edges + d->n_halo_msgs) { set_error("rev_local entry outside the message buffer"); return SBMBP_ERR_ARG; }
     if (d->n_own == 0 || d->n_global == 0) { set_error("empty shard"); return SBMBP_ERR_ARG; }
     if (d->row_ptr[0] != 0 || d->row_ptr[d->n_own] != d->n_edges || d->n_edges >= (uint64_t(1) << 32)) { set_error("shard row_ptr does not span [0, n_edges]"); return SBMBP_ERR_ARG; }
     const uint64_t table_rows = uint64_t(d->n_own) + d->n_halo;
@@ -1331,6 +1345,7 @@ int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *d, uint32_t
     e->d_psi[0] = static_cast<double *>(d->psi_buf0);
     e->d_psi[1] = static_cast<double *>(d->psi_buf1);
     e->d_red = static_cast<double *>(d->red_buf);
+    e->n_halo_msgs = d->n_halo_msgs;
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->own_stream = true;
     const uint32_t cap = uint32_t(frame_cap(Q)), rcap = uint32_t(frame_rcap(Q));
@@ -1385,11 +1400,29 @@ int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *d, uint32_t
     TRY(dev_alloc(e, &e->d_hub_row, hub_row.size()));
     TRY(dev_alloc(e, &e->d_hub_blk, hub_blk.size()));
     TRY(dev_alloc(e, &e->d_true, e->N));
-    TRY(dev_alloc(e, &e->d_M[0], std::max<uint64_t>(e->E2, 1) * (Q - 1)));  // records of Q-1 components; >= one record: the sweep's loads are branch-free
-    TRY(dev_alloc(e, &e->d_M[1], std::max<uint64_t>(e->E2, 1) * (Q - 1)));
+    TRY(dev_alloc(e, &e->d_clamp, e->N));
+    // records of Q-1 components; >= one record: the sweep's loads are branch-free. With a reverse index the records received
+    // from the peers (the incoming messages of the cut edges) live behind the own ones, so rev addresses one array.
+    TRY(dev_alloc(e, &e->d_M[0], std::max<uint64_t>(e->E2 + e->n_halo_msgs, 1) * (Q - 1)));
+    TRY(dev_alloc(e, &e->d_M[1], std::max<uint64_t>(e->E2 + e->n_halo_msgs, 1) * (Q - 1)));
     TRY(dev_alloc(e, &e->d_P, 1));
     e->hist_cap = 4096;
     TRY(dev_alloc(e, &e->d_hist, e->hist_cap));
+    if (d->rev_local) {
+        TRY(dev_alloc(e, &e->d_rev, e->E2));
+        if (e->E2) TRYHIP(hipMemcpyAsync(e->d_rev, d->rev_local, e->E2 * 4, hipMemcpyHostToDevice, e->stream));
+        else TRYHIP(hipMemsetAsync(e->d_rev, 0, 4, e->stream));
+    }
+    if (dc == 2) {
+        TRY(dev_alloc(e, &e->d_deg, size_t(d->n_own) + d->n_halo));
+        TRYHIP(hipMemcpyAsync(e->d_deg, d->table_deg, (size_t(d->n_own) + d->n_halo) * 4, hipMemcpyHostToDevice, e->stream));
+        TRY(dev_alloc(e, &e->d_src, e->E2));
+    }
+    TRYHIP(hipMemsetAsync(e->d_clamp, 0xff, size_t(e->N) * 4, e->stream));
+    if (e->n_halo_msgs) {  // defined content before the first exchange
+        TRYHIP(hipMemsetAsync(e->d_M[0] + e->E2 * (Q - 1), 0, e->n_halo_msgs * (Q - 1) * 8, e->stream));
+        TRYHIP(hipMemsetAsync(e->d_M[1] + e->E2 * (Q - 1), 0, e->n_halo_msgs * (Q - 1) * 8, e->stream));
+    }
     TRY(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 64)) * (QMAX + 1)));
     TRY(ensure_small(e, 8192));
     TRY(dev_alloc(e, &e->d_stage, size_t(FOLD_BLOCKS) * FOLD_STRIDE_MAX));
@@ -1406,6 +1439,12 @@ int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *d, uint32_t
     }
     TRYHIP(hipMemsetAsync(e->d_true, 0, size_t(e->N) * 4, e->stream));
     TRYHIP(hipMemsetAsync(e->d_partials, 0, e->partials_cap * 8, e->stream));
+    if (dc == 2) hipLaunchKernelGGL(k_fill_src, dim3((e->N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->N, e->d_src);
+    if (dc == 1) {  // sum over the owned rows of 2 d log d (their share of the dc 1 constant of f_site / f_edge)
+        double sdl = 0.0;
+        for (uint32_t i = 0; i < d->n_own; ++i) { const double dg = double(rp32[i + 1] - rp32[i]); if (dg > 0) sdl += 2.0 * dg * std::log(dg); }
+        e->sum_log_didl = sdl;
+    }
     TRYHIP(hipStreamSynchronize(e->stream));
 #undef TRY
 #undef TRYHIP
@@ -1413,11 +1452,130 @@ int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *d, uint32_t
     return SBMBP_OK;
 }
 
-int sbmbp_shard_begin(sbmbp_engine_t *e, double crit) {
+int sbmbp_shard_set_labels(sbmbp_engine_t *e, const int32_t *conf, const uint32_t *true_conf, uint32_t flag, int conditional,
+                           int any_clamp_global) {
+    IS_SHARD(e);
+    CHK(upload_labels(e, conf, true_conf, flag, conditional));
+    // whether clamped rows exist is a property of the whole graph: every shard takes the same kernel variants
+    e->has_clamp = any_clamp_global != 0;
+    e->clamp_onehot = e->has_clamp && (flag == 1 || flag == 3);
+    return SBMBP_OK;
+}
+
+int sbmbp_shard_query(sbmbp_engine_t *e, int what) {
+    if (!e) return SBMBP_ERR_ARG;
+    switch (what) {
+        case 0: return e->w_positive ? 1 : 0;
+        case 1: return e->has_clamp ? 1 : 0;
+        case 2: return e->clamp_onehot ? 1 : 0;
+        case 3: return e->init_from_psi ? 1 : 0;
+        case 4: return e->d_rev ? 1 : 0;
+        default: return SBMBP_ERR_ARG;
+    }
+}
+
+int sbmbp_shard_set_incoming(sbmbp_engine_t *e, int source) {
+    IS_SHARD(e);
+    if (source != 0 && !(source == 1 && e->d_rev)) return SBMBP_ERR_ARG;
+    e->incoming_src = source;
+    return SBMBP_OK;
+}
+
+void *sbmbp_shard_msg_halo(sbmbp_engine_t *e, uint32_t j) {
+    if (!e || !e->sharded) return nullptr;
+    return e->d_M[(e->cur + int(j)) & 1] + e->E2 * (e->Q - 1);
+}
+
+int sbmbp_shard_pack_msgs(sbmbp_engine_t *e, uint32_t j, const uint32_t *d_edge_idx, uint32_t n, double *d_out) {
+    IS_SHARD(e);
+    if (n == 0) return SBMBP_OK;
+    const int mc = int(e->Q) - 1;  // records are rows of Q-1 words: the generic row gather copies them verbatim
+    const uint64_t tot = uint64_t(n) * mc;
+    hipLaunchKernelGGL(k_pack_rows, dim3(uint32_t((tot + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, e->stream, e->d_M[(e->cur + int(j)) & 1],
+                       d_edge_idx, n, mc, mc, d_out);
+    HIPCHK(hipGetLastError());
+    return SBMBP_OK;
+}
+
+// message-gather form of sweep j on a shard (any damping, clamped rows, dc 2, zeros in cab): incoming messages of the cut
+// edges are read from the records the caller received behind the own ones (sbmbp_shard_msg_halo of the same j)
+int sbmbp_shard_sweep_explicit(sbmbp_engine_t *e, uint32_t j, double damping) {
+    IS_SHARD(e);
+    if (!e->d_rev) { set_error("shard was created without a reverse index"); return SBMBP_ERR_STATE; }
+    const int mc = (e->cur + int(j)) & 1, pc = (e->pcur + int(j)) & 1;
+    const double *Mold = e->d_M[mc];
+    double *Mnew = e->d_M[mc ^ 1];
+    const double *psi_old = e->d_psi[pc];
+    double *psi_new = e->d_psi[pc ^ 1];
+    const int32_t *clamp = e->has_clamp ? e->d_clamp : nullptr;
+    CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (e->Q + 1)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (e->timing && e->n_blk) {
+        if (e->ev_used + 2 > e->ev.size()) {
+            size_t old = e->ev.size();
+            e->ev.resize(old + 256);
+            for (size_t i = old; i < e->ev.size(); ++i) HIPCHK(hipEventCreate(&e->ev[i]));
+        }
+        e0 = e->ev[e->ev_used++];
+        e1 = e->ev[e->ev_used++];
+        HIPCHK(hipEventRecord(e0, e->stream));
+    }
+    if (e->n_blk) {
+        if (e->dc == 2) {
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, true>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_rev, e->d_nbr,
+                                                e->d_deg, Mold, Mnew, psi_old, psi_new, clamp, e->d_blk_row, e->d_blk_e0, e->d_P, 1, damping, e->d_partials));
+        } else {
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, false>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_rev, e->d_nbr,
+                                                e->d_deg, Mold, Mnew, psi_old, psi_new, clamp, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), damping, e->d_partials));
+        }
+    }
+    if (e0) HIPCHK(hipEventRecord(e1, e->stream));
+    if (e->n_hub) {
+        if (e->dc == 2) {
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_rev, e->d_nbr,
+                                                e->d_deg, Mold, Mnew, psi_old, psi_new, clamp, e->d_hub_row, e->d_hub_blk, e->d_P, 1, damping, e->d_partials));
+        } else {
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, false>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_rev, e->d_nbr,
+                                                e->d_deg, Mold, Mnew, psi_old, psi_new, clamp, e->d_hub_row, e->d_hub_blk, e->d_P, int(e->dc), damping, e->d_partials));
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return SBMBP_OK;
+}
+
+// the convergence state without blocking the host: record copies it into page-locked slot 0/1 behind the work queued so
+// far, wait blocks until that point of the stream and returns it
+int sbmbp_shard_state_record(sbmbp_engine_t *e, int slot) {
+    IS_SHARD(e);
+    if (slot < 0 || slot > 1) return SBMBP_ERR_ARG;
+    if (!e->h_cs) {
+        HIPCHK(hipHostMalloc(&e->h_cs, 2 * sizeof(conv_state), hipHostMallocDefault));
+        for (auto &ev : e->ev_cs) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    conv_state *slots = static_cast<conv_state *>(e->h_cs);
+    HIPCHK(hipMemcpyAsync(&slots[slot], reinterpret_cast<const char *>(e->d_P) + offsetof(dev_params, maxdiff), sizeof(conv_state),
+                          hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipEventRecord(e->ev_cs[slot], e->stream));
+    return SBMBP_OK;
+}
+int sbmbp_shard_state_wait(sbmbp_engine_t *e, int slot, sbmbp_conv_state *out) {
+    IS_SHARD(e);
+    if (slot < 0 || slot > 1 || !out || !e->h_cs) return SBMBP_ERR_ARG;
+    HIPCHK(hipEventSynchronize(e->ev_cs[slot]));
+    const conv_state &cs = static_cast<conv_state *>(e->h_cs)[slot];
+    out->maxdiff = cs.maxdiff;
+    out->conv_iter = cs.conv_iter;
+    out->sweep_idx = cs.sweep_idx;
+    out->stop = cs.stop;
+    out->last_exact = cs.last_exact;
+    return SBMBP_OK;
+}
+
+int sbmbp_shard_begin(sbmbp_engine_t *e, double crit, int hinted) {
     IS_SHARD(e);
     if (!e->have_params || !e->have_state) { set_error("set_params and an initial state must precede shard sweeps"); return SBMBP_ERR_STATE; }
-    if (!e->w_positive) { set_error("sharded engines need every cab entry > 0"); return SBMBP_ERR_UNSUPPORTED; }
-    return upload_params(e, crit, true);
+    if (hinted && !e->w_positive) { set_error("the marginal-gather sweep needs every cab entry > 0"); return SBMBP_ERR_UNSUPPORTED; }
+    return upload_params(e, crit, hinted != 0);
 }
 
 int sbmbp_shard_read_buffer(sbmbp_engine_t *e, uint32_t j) { return (e && e->sharded) ? ((e->pcur + int(j)) & 1) : SBMBP_ERR_ARG; }
@@ -1546,10 +1704,10 @@ int sbmbp_shard_sweep_partial(sbmbp_engine_t *e, uint32_t j) {
     return sbmbp_shard_sweep_fold(e);
 }
 
-int sbmbp_shard_finalize(sbmbp_engine_t *e, int mode, uint32_t n_rows) {
+int sbmbp_shard_finalize(sbmbp_engine_t *e, int mode, uint32_t n_rows, int md_exact) {
     IS_SHARD(e);
     if ((mode != 0 && mode != 1) || n_rows == 0 || SBMBP_RED_GATHER_OFFSET + uint64_t(n_rows) * (e->Q + 1) > 8192) return SBMBP_ERR_ARG;
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, e->stream, e->d_red + SBMBP_RED_GATHER_OFFSET, n_rows, int(e->Q), mode, e->d_P, e->d_hist, e->hist_cap, 0);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, e->stream, e->d_red + SBMBP_RED_GATHER_OFFSET, n_rows, int(e->Q), mode, e->d_P, e->d_hist, e->hist_cap, md_exact);
     HIPCHK(hipGetLastError());
     return SBMBP_OK;
 }
@@ -1607,6 +1765,7 @@ int sbmbp_shard_commit(sbmbp_engine_t *e, uint32_t executed) {
 
 // ---- reductions on shards: partial -> (caller all-reduces red) -> finish ----------------------------
 static int shard_materialize(sbmbp_engine_t *e) {
+    if (e->incoming_src == 1) return SBMBP_OK;  // the reductions gather the incoming messages through rev (halo records in place)
     if (!e->d_Min) CHK(dev_alloc(e, &e->d_Min, e->E2 * (e->Q - 1)));
     if (e->E2 == 0) return SBMBP_OK;
     const uint32_t nb = uint32_t(std::min<uint64_t>(4096, (e->E2 + BLOCK - 1) / BLOCK));
@@ -1645,9 +1804,7 @@ int sbmbp_shard_fe_partial(sbmbp_engine_t *e, int want_entropy) {
     CHK(shard_materialize(e));
     double dummy[4];
     CHK(site_edge_terms(e, want_entropy != 0, dummy, e->d_red));
-    double c = 0.0;
-    if (e->dc == 1)
-        for (uint32_t i = 0; i < e->N; ++i) { const double d = double(e->h_row_ptr[i + 1] - e->h_row_ptr[i]); if (d > 0) c += 2.0 * d * std::log(d); }
+    const double c = e->dc == 1 ? e->sum_log_didl : 0.0;
     HIPCHK(hipMemcpyAsync(e->d_red + 4, &c, 8, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));  // c is a stack object
     return SBMBP_OK;
@@ -1779,8 +1936,14 @@ int sbmbp_shard_em_partial(sbmbp_engine_t *e, uint32_t *n_values) {
     CHK(sbmbp_shard_rowsums_partial(e));
     const uint32_t nb = uint32_t(std::min<uint64_t>(2048, std::max<uint64_t>(1, (e->E2 + BLOCK - 1) / BLOCK)));
     CHK(ensure_partials(e, size_t(nb) * (T + 1)));
-    DISPATCH_Q(Q, hipLaunchKernelGGL((k_em_edges<QQ, false>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_rev, e->d_nbr,
-                                     e->d_src, e->d_M[e->cur], e->d_Min, uint32_t(e->E2), e->d_P, e->d_partials));
+    const double *Min = e->incoming_src == 0 ? e->d_Min : nullptr;
+    if (e->dc == 2) {
+        DISPATCH_Q(Q, hipLaunchKernelGGL((k_em_edges<QQ, true>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_rev, e->d_nbr, e->d_deg,
+                                         e->d_src, e->d_M[e->cur], Min, uint32_t(e->E2), e->d_P, e->d_partials));
+    } else {
+        DISPATCH_Q(Q, hipLaunchKernelGGL((k_em_edges<QQ, false>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_rev, e->d_nbr, e->d_deg,
+                                         e->d_src, e->d_M[e->cur], Min, uint32_t(e->E2), e->d_P, e->d_partials));
+    }
     HIPCHK(hipGetLastError());
     CHK(fold_to_device(e, nb, T, T + 1, e->d_red + R));
     *n_values = R + T;

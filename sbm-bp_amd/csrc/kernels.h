@@ -499,7 +499,7 @@ __device__ __forceinline__ void edge_field(const dev_params *__restrict__ P, con
 // ------------------------------------------------------------------------------------------------
 template <int Q, bool DC2>
 __global__ void __launch_bounds__(FTPB)
-k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr,
+k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr, const uint32_t *__restrict__ ndeg /* degree of every table row (DC2 only) */,
         const double *__restrict__ Mold, double *__restrict__ Mnew, const double *__restrict__ psi_old,
         double *__restrict__ psi, const int32_t *__restrict__ clamp, const uint32_t *__restrict__ blk_row,
         const uint32_t *__restrict__ blk_e0, const dev_params *__restrict__ P, int dc, double damp, double *__restrict__ partials) {
@@ -559,7 +559,7 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
             if (DC2) {
                 const int r = srow[le];
                 const uint32_t l = nbr[e0 + le];
-                didl = double(srp[r + 1] - srp[r]) * double(row_ptr[l + 1] - row_ptr[l]);
+                didl = double(srp[r + 1] - srp[r]) * double(ndeg[l]);
             }
             double b[Q];
             edge_field<Q, DC2>(P, mi[j], didl, b);
@@ -1119,7 +1119,7 @@ k_msg_diff(const double *__restrict__ a, const double *__restrict__ b, uint64_t 
 // ------------------------------------------------------------------------------------------------
 template <int Q, bool DC2>
 __global__ void __launch_bounds__(BLOCK)
-k_sweep_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr,
+k_sweep_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr, const uint32_t *__restrict__ ndeg /* degree of every table row (DC2 only) */,
             const double *__restrict__ Mold, double *__restrict__ Mnew, const double *__restrict__ psi_old,
             double *__restrict__ psi, const int32_t *__restrict__ clamp, const uint32_t *__restrict__ hub_row,
             const uint32_t *__restrict__ hub_blk, const dev_params *__restrict__ P, int dc, double damp,
@@ -1159,7 +1159,7 @@ k_sweep_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ r
             double m[Q], b[Q];
             load_msg<Q>(Mold, rev[e0 + le], m);
             double didl = 0.0;
-            if (DC2) { const uint32_t l = nbr[e0 + le]; didl = di * double(row_ptr[l + 1] - row_ptr[l]); }
+            if (DC2) { const uint32_t l = nbr[e0 + le]; didl = di * double(ndeg[l]); }
             edge_field<Q, DC2>(P, m, didl, b);
 #pragma unroll
             for (int q = 0; q < Q; ++q) A[q] *= b[q];
@@ -1179,7 +1179,7 @@ k_sweep_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ r
             load_msg<Q>(Mold, rev[e0 + le], m);
             load_msg<Q>(Mold, size_t(e0 + le), mo);
             double didl = 0.0;
-            if (DC2) { const uint32_t l = nbr[e0 + le]; didl = di * double(row_ptr[l + 1] - row_ptr[l]); }
+            if (DC2) { const uint32_t l = nbr[e0 + le]; didl = di * double(ndeg[l]); }
             edge_field<Q, DC2>(P, m, didl, b);
             double ct = 0.0, cav[Q];
 #pragma unroll
@@ -1317,7 +1317,7 @@ __device__ __forceinline__ void edge_terms(const dev_params *__restrict__ P, con
 
 template <int Q, bool DC2>
 __global__ void __launch_bounds__(FTPB)
-k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr,
+k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr, const uint32_t *__restrict__ ndeg /* degree of every table row (DC2 only) */,
            const double *__restrict__ M, const double *__restrict__ Min /* incoming messages in edge order, or null: gather M[rev] */,
            const uint32_t *__restrict__ blk_row, const dev_params *__restrict__ P,
            int dc, int want_entropy, double *__restrict__ partials) {
@@ -1350,7 +1350,7 @@ k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
                 if (DC2) {
                     const int r = srow[le];
                     const uint32_t l = nbr[e0 + le];
-                    didl = double(srp[r + 1] - srp[r]) * double(row_ptr[l + 1] - row_ptr[l]);
+                    didl = double(srp[r + 1] - srp[r]) * double(ndeg[l]);
                 }
                 edge_field<Q, DC2>(P, mi, didl, b);
                 store_vec<Q>(&sb[le * Q], b);
@@ -1406,7 +1406,7 @@ k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
 
 template <int Q, bool DC2>
 __global__ void __launch_bounds__(BLOCK)
-k_fe_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr,
+k_fe_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr, const uint32_t *__restrict__ ndeg /* degree of every table row (DC2 only) */,
          const double *__restrict__ M, const double *__restrict__ Min, const uint32_t *__restrict__ hub_row,
          const uint32_t *__restrict__ hub_blk, const dev_params *__restrict__ P, int dc, int want_entropy,
          double *__restrict__ partials) {
@@ -1428,7 +1428,7 @@ k_fe_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev,
         load_msg<Q>(Min ? Min : M, Min ? size_t(e0 + le) : size_t(rev[e0 + le]), mi);
         load_msg<Q>(M, size_t(e0 + le), mo);
         double didl = 0.0;
-        if (DC2) { const uint32_t l = nbr[e0 + le]; didl = di * double(row_ptr[l + 1] - row_ptr[l]); }
+        if (DC2) { const uint32_t l = nbr[e0 + le]; didl = di * double(ndeg[l]); }
         edge_field<Q, DC2>(P, mi, didl, b);
 #pragma unroll
         for (int q = 0; q < Q; ++q) A[q] *= b[q];
@@ -1728,7 +1728,7 @@ k_nonedge_exact_adj(const uint32_t *__restrict__ row_ptr, const uint32_t *__rest
 // ------------------------------------------------------------------------------------------------
 template <int Q, bool DC2>
 __global__ void __launch_bounds__(BLOCK)
-k_em_edges(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr,
+k_em_edges(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr, const uint32_t *__restrict__ ndeg /* degree of every table row (DC2 only) */,
            const uint32_t *__restrict__ src /* row of each edge, DC2 only */, const double *__restrict__ M,
            const double *__restrict__ Min, uint32_t n_edges, const dev_params *__restrict__ P,
            double *__restrict__ partials /* [grid][Q*Q] */) {
@@ -1744,7 +1744,7 @@ k_em_edges(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
         double didl = 0.0;
         if (DC2) {
             const uint32_t i = src[k], l = nbr[k];
-            didl = double(row_ptr[i + 1] - row_ptr[i]) * double(row_ptr[l + 1] - row_ptr[l]);
+            didl = double(row_ptr[i + 1] - row_ptr[i]) * double(ndeg[l]);
         }
         double term[T], norm_L = 0.0;
         int t = 0;

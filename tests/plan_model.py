@@ -1,4 +1,5 @@
-"""Vertex-range sharding plan (host logic, numpy only).
+"""TEST INFRASTRUCTURE — numpy restatement of the vertex-range sharding plan of csrc/dist.hip (build_plan), against which
+the C++ plan is checked array for array (tests/test_sharded_cpu.py). Never imported by the product.
 
 Each shard owns a contiguous row range, chosen so that sum(deg + 2) is balanced; its marginal
 table is [owned rows | halo vertices], halo vertices sorted by global id (hence grouped by owner,
@@ -35,67 +36,6 @@ def chunk_rows(row_ptr_local, n_chunks):
         cuts.append(min(max(b, cuts[-1]), n))
     cuts.append(n)
     return np.array(cuts, dtype=np.int64)
-
-
-def block_cyclic_layout(row_ptr, world, k):
-    """Cut the rows into k*world blocks (balanced like partition_rows) and deal them round robin: shard s gets blocks
-    s, s + world, ...  Returns (order, bounds): `order[p]` = old id of the vertex at new position p (each shard's
-    vertices contiguous, blocks in ascending old order) and the shard boundaries in the new numbering.
-    Why: over a point-to-point mesh the exchange is bound by the BUSIEST link, not by the cut. With planted or otherwise
-    contiguous communities, plain ranges put most of a shard's boundary traffic on the one peer that holds the rest
-    of its community; dealing blocks spreads every community over several shards and evens the links out."""
-    row_ptr = np.asarray(row_ptr, dtype=np.int64)
-    bb = partition_rows(row_ptr, k * world)
-    pieces, bounds = [], [0]
-    for s in range(world):
-        for j in range(k):
-            b = j * world + s
-            pieces.append(np.arange(bb[b], bb[b + 1], dtype=np.int64))
-        bounds.append(bounds[-1] + sum(int(bb[j * world + s + 1] - bb[j * world + s]) for j in range(k)))
-    return np.concatenate(pieces), np.array(bounds, dtype=np.int64), bb
-
-
-def busiest_link_rows(row_ptr, nbr, world, k, rank):
-    """rows shard `rank` would send to its busiest peer under block_cyclic_layout(k) (k = 1: plain ranges), from its own
-    rows alone: the number of (own vertex, peer) pairs with at least one edge, per peer"""
-    row_ptr = np.asarray(row_ptr, dtype=np.int64)
-    bb = partition_rows(row_ptr, k * world)
-    best = np.zeros(world, dtype=np.int64)
-    for j in range(k):
-        b = j * world + rank
-        lo, hi = int(bb[b]), int(bb[b + 1])
-        nb = np.asarray(nbr[row_ptr[lo]:row_ptr[hi]], dtype=np.int64)
-        owner = (np.searchsorted(bb, nb, side="right") - 1) % world
-        src = np.repeat(np.arange(hi - lo, dtype=np.int64), np.diff(row_ptr[lo:hi + 1]))
-        key = np.unique(owner * np.int64(max(hi - lo, 1)) + src)
-        best += np.bincount(key // max(hi - lo, 1), minlength=world)[:world]
-    best[rank] = 0
-    return int(best.max()) if world > 1 else 0
-
-
-def permute_csr(row_ptr, nbr, order, block_bounds):
-    """the same graph with vertex `order[p]` renamed p; rows keep their internal edge order"""
-    row_ptr = np.asarray(row_ptr, dtype=np.int64)
-    n = len(row_ptr) - 1
-    inv = np.empty(n, dtype=np.int64)
-    inv[order] = np.arange(n, dtype=np.int64)
-    deg = np.diff(row_ptr)[order]
-    row_ptr2 = np.concatenate([[0], np.cumsum(deg)]).astype(np.uint64)
-    # `order` is a concatenation of contiguous blocks: move the edge slices block by block, then rename the targets
-    starts = np.flatnonzero(np.concatenate([[True], np.diff(order) != 1])) if n else np.zeros(0, dtype=np.int64)
-    ends = np.append(starts[1:], n)
-    parts = [np.asarray(nbr[row_ptr[order[a]]:row_ptr[order[b - 1] + 1]]) for a, b in zip(starts, ends) if b > a]
-    nbr_old = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint32)
-    return row_ptr2, inv[nbr_old.astype(np.int64)].astype(np.uint32), inv
-
-
-def edge_order(row_ptr, order):
-    """old index of every directed edge in the renamed graph (rows move as wholes): state arrays per edge follow it"""
-    row_ptr = np.asarray(row_ptr, dtype=np.int64)
-    deg = np.diff(row_ptr)[order]
-    start = np.repeat(row_ptr[order], deg)
-    first = np.repeat(np.concatenate([[0], np.cumsum(deg)])[:-1], deg)
-    return start + (np.arange(int(deg.sum()), dtype=np.int64) - first)
 
 
 class ShardPlan:

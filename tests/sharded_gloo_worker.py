@@ -11,9 +11,10 @@ for p in (ROOT, HERE, os.path.join(ROOT, "oracle")):
     sys.path.insert(0, p)
 
 import oracle as orc  # noqa: E402
+import sbm_bp_amd as S  # noqa: E402
 from conftest import args_of, golden  # noqa: E402
-from sbm_bp_amd.distributed import ShardedBP, TorchDistComm  # noqa: E402
 from shard_numpy_backend import NumpyShardBackend  # noqa: E402
+from shard_protocol_model import CppPlan, ProtocolModel, TorchDistComm  # noqa: E402
 
 
 def main():
@@ -25,12 +26,13 @@ def main():
     cab, na = orc.param_from_direct(a["N"], a["Q"], a["pa"], a["cab_upper"])
     psi0, msg0 = bp.get_state()
     comm = TorchDistComm()
-    sb = ShardedBP.from_csr(g.row_ptr, g.nbr, a["Q"], a["dc"], comm, backend_factory=lambda p: NumpyShardBackend(p, a["Q"], a["dc"]))
+    plan = CppPlan(S.Graph.from_csr(g.row_ptr, g.nbr, g.rev), comm.world, comm.rank, 4)  # this rank's plan, built in C++
+    sb = ProtocolModel([plan], a["Q"], a["dc"], comm, backend_factory=lambda p: NumpyShardBackend(p, a["Q"], a["dc"]))
     sb.shards[0].init_from_global(psi0, msg0, a["true_conf"])
     sb.expand_bp_params(cab, na, a["beta"])
     niter, exact = sb.converge(1e-12, 3000, 1.0, check_every=4)
     ov = sb.compute_overlap()
-    psi_local = sb.local_state()[0][0]
+    psi_local = sb.shards[0].get_state()[0]
     gathered = [None] * comm.world
     dist.all_gather_object(gathered, psi_local)
     if comm.rank == 0:

@@ -1,5 +1,5 @@
 """worker of tests/test_gpu_sharded.py::test_three_processes_share_one_gpu (launched by torch.distributed.run):
-one HIP shard per process, all on cuda:0, collectives over gloo staged through the host (HostStagedComm)."""
+one rank of the C++ driver per process, all on cuda:0, the callback transport over gloo (buffers staged through the host)."""
 import os
 import sys
 
@@ -13,8 +13,9 @@ for p in (ROOT, HERE, os.path.join(ROOT, "oracle")):
     sys.path.insert(0, p)
 
 import oracle as orc  # noqa: E402
+import sbm_bp_amd as S  # noqa: E402
 from conftest import args_of, golden  # noqa: E402
-from sbm_bp_amd.distributed import HostStagedComm, ShardedBP  # noqa: E402
+from sbm_bp_amd.distributed import Comm, ShardedBP  # noqa: E402
 
 
 def main():
@@ -27,23 +28,24 @@ def main():
     bp.init_messages(0, None, a["true_conf"], orc.Rng(a["seed"]))
     cab, na = orc.param_from_direct(a["N"], a["Q"], a["pa"], a["cab_upper"])
     psi0, msg0 = bp.get_state()
-    comm = HostStagedComm()
-    sb = ShardedBP.from_csr(g.row_ptr, g.nbr, a["Q"], a["dc"], comm)
-    assert sb.plans[0].n_chunks == 4  # the chunked exchange of the multi-rank path
-    p = sb.plans[0]
+    comm = Comm.callbacks_from_torch()
+    sb = ShardedBP(S.Graph.from_csr(g.row_ptr, g.nbr), a["Q"], a["dc"], comm, device=0)
+    assert sb.info.n_chunks == 4 and comm.transport == "callbacks"  # the chunked exchange of the multi-rank path
+    e0 = int(g.row_ptr[sb.row0])
     sb.init_messages_device(7, a["true_conf"])
-    sb.shards[0].set_state(psi0[p.row0:p.row0 + p.n_own], msg0[p.edge0:p.edge0 + p.n_edges])
+    sb.set_state(psi0[sb.row0:sb.row0 + sb.n_own], msg0[e0:e0 + sb.n_edges])
     sb.expand_bp_params(cab, na, a["beta"])
     d3 = sb.sweep(3)
     niter, exact = sb.converge(1e-12, 3000, 1.0, check_every=6)
     ov = sb.compute_overlap()
     fe = sb.compute_free_energy()
     ent = sb.compute_entropy()
-    psi_local = sb.local_state()[0][0]
+    psi_local = sb.get_state()[0]
     gathered = [None] * comm.world
     dist.all_gather_object(gathered, psi_local)
     if comm.rank == 0:
         np.savez(out, d3=d3, niter=niter, exact=exact, overlap=ov, fe=fe, entropy=ent, psi=np.concatenate(gathered))
+    sb.close()
     dist.barrier()
     dist.destroy_process_group()
 

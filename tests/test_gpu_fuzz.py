@@ -146,40 +146,48 @@ def test_random_instance_against_the_oracle(S, orc, seed):
 
 
 @pytest.mark.parametrize("seed", _seeds("SBMBP_FUZZ_SHARD_SEEDS", (200, 30)))
-def test_random_instance_sharded_against_one_shard(S, seed):
-    """the sharded engine (2-5 HIP shards in this process, chunked exchange) against a single shard on random instances:
-    iterates to 1e-12, then free energy, entropy, EM expectations, overlap"""
-    from sbm_bp_amd.distributed import LocalComm, ShardedBP
+def test_random_instance_sharded_against_the_single_engine(S, seed):
+    """the multi-GPU driver (2-5 ranks as threads on this GPU, chunked exchange) against the single engine on the SAME random
+    instances as above - every sweep form: marginal gather, and message gather for damping, clamped rows, dc 2, zeros in
+    cab. Iterates to 1e-12, then free energy, entropy, EM expectations, overlap."""
+    from sbm_bp_amd.distributed import LocalShards
     t = _instance(seed)
     rng = np.random.default_rng(seed)
-    Q, N, dc = t["Q"], max(t["N"], 12), min(t["dc"], 1)  # shards: marginal-gather form (dc 0/1, cab > 0, no clamps)
-    if N != t["N"]:
-        t["pairs"] = (t["pairs"] % N).astype(np.uint32)
-        t["tc"] = rng.integers(0, Q, size=N).astype(np.uint32)
-    cab = np.where(t["cab"] == 0, t["cab"][t["cab"] > 0].min(), t["cab"])
-    if dc != t["dc"]:
-        cab = cab * t["cab"].max() ** -1 * 0.01
+    Q, N, dc = t["Q"], t["N"], t["dc"]
     world = int(rng.integers(2, 6))
+    if N < world:
+        pytest.skip("fewer vertices than ranks")
     g = S.Graph.from_edges(t["pairs"], N)
-    row_ptr, nbr, _ = g.csr()
-    runs = []
-    for w in (1, world):
-        sb = ShardedBP.from_csr(row_ptr, nbr, Q, dc, LocalComm(w), n_chunks=int(rng.integers(1, 5)) if w > 1 else 1)
-        sb.init_messages_device(seed, t["tc"])
-        sb.expand_bp_params(cab, t["na"], 1.0)
-        d = [sb.sweep(1) for _ in range(3)]
-        psi = np.concatenate([s[0] for s in sb.local_state()])
-        msg = np.concatenate([s[1] for s in sb.local_state()])
-        fe = sb.compute_free_energy()
-        en = sb.compute_entropy()
-        em = sb.em_expectations()
-        runs.append((d, psi, msg, fe, en, em, sb.compute_overlap()))
-    (d1, p1, m1, f1, e1, em1, o1), (dk, pk, mk, fk, ek, emk, ok) = runs
-    assert np.abs(np.array(d1) - np.array(dk)).max() < 1e-12
-    assert np.abs(p1 - pk).max() < 1e-12 and (m1.size == 0 or np.abs(m1 - mk).max() < 1e-12)
-    assert _close(fk, f1, 1e-10) and _close(ek, e1, 1e-9) and abs(o1 - ok) < 1e-12
-    for a, b in zip(emk, em1):
-        assert _close(a, b, 1e-9)
+    bp = S.bp_conditional()
+    bp.init_messages(S.blockmodel_t(g, Q, dc), t["flag"], t["conf"], t["tc"], t["seed"])
+    bp.set_beta(t["beta"])
+    bp.expand_bp_params(S.bp_blockmodel_state(t["cab"], t["na"]))
+    sb = LocalShards(g, Q, dc, world, n_chunks=int(rng.integers(1, 5)))
+    sb.init_messages(t["flag"], t["conf"], t["tc"], t["seed"], True)
+    sb.expand_bp_params(t["cab"], t["na"], t["beta"])
+    for k in range(4):
+        damp = t["damp"] if k < 2 else 1.0
+        d1, dk = bp.sweep(1, damp), sb.sweep(1, damp)
+        p1, m1 = bp.get_state()
+        pk, mk = sb.global_state()
+        if np.isnan(m1).any() or np.isnan(p1).any():  # contradictory hard constraints (see above): same NaN pattern
+            assert (np.isnan(pk) == np.isnan(p1)).all() and (np.isnan(mk) == np.isnan(m1)).all()
+            sb.close()
+            return
+        assert abs(d1 - dk) < 1e-12, "sweep %d" % k
+        assert np.abs(p1 - pk).max() < 1e-12 and (m1.size == 0 or np.abs(m1 - mk).max() < 1e-12), "sweep %d" % k
+    f1, fk = bp.compute_free_energy(parts=True)[1], sb.compute_free_energy(parts=True)[1]
+    assert _close(fk, f1, 1e-10), (fk, f1)
+    e1, ek = bp.compute_entropy(), sb.compute_entropy()
+    assert (np.isnan(e1) and np.isnan(ek)) or _close(ek, e1, 1e-9)
+    for x, y in zip(sb.em_expectations(), bp.em_expectations()):
+        assert _close(x, y, 1e-9)
+    assert abs(bp.compute_overlap() - sb.compute_overlap()) < 1e-12
+    it1, last1 = bp.converge(1e-9, 400, 1.0)
+    itk, lastk = sb.converge(1e-9, 400, 1.0)
+    if not (np.isnan(last1) or np.isnan(lastk)):
+        assert it1 == itk or min(last1, lastk) < 4e-9, (it1, itk, last1, lastk)
+    sb.close()
 
 
 @pytest.mark.parametrize("seed", _seeds("SBMBP_FUZZ_LEARN_SEEDS", (500, 24)))
@@ -222,10 +230,11 @@ def test_random_instance_learning_against_the_oracle(S, orc, seed):
 
 
 @pytest.mark.parametrize("seed", _seeds("SBMBP_FUZZ_SHARD_LEARN_SEEDS", (800, 10)))
-def test_random_instance_sharded_learning_against_one_shard(S, seed):
-    """-m learn over 2-4 shards (chunked exchange, fused send/receive buffers) follows the single shard's EM run"""
+def test_random_instance_sharded_learning_against_the_single_engine(S, seed):
+    """-m learn over 2-4 ranks follows the single engine's EM run (same schedule; only the summation order of the Q field sums
+    differs, which an EM run of tens of steps can amplify up to one vertex in the truncated group sizes)"""
     from sbm_bp_amd import synth
-    from sbm_bp_amd.distributed import LocalComm, ShardedBP
+    from sbm_bp_amd.distributed import LocalShards
     rng = np.random.default_rng(9000 + seed)
     Q = int(rng.choice([2, 3, 4]))
     N = int(rng.choice([300, 600, 1200])) // Q * Q
@@ -235,16 +244,18 @@ def test_random_instance_sharded_learning_against_one_shard(S, seed):
     cab0 = synth.cab_matrix(Q, cin * rng.uniform(0.8, 1.2), cout * rng.uniform(0.8, 1.5))
     na = np.array(synth.group_sizes(N, Q), dtype=np.uint32)
     g = S.Graph.from_edges(pairs, N)
-    row_ptr, nbr, _ = g.csr()
-    out = []
-    for w in (1, int(rng.integers(2, 5))):
-        sb = ShardedBP.from_csr(row_ptr, nbr, Q, 0, LocalComm(w), n_chunks=int(rng.integers(1, 5)) if w > 1 else 1)
-        sb.init_messages_device(seed, tc)
-        sb.expand_bp_params(cab0, na, 1.0)
-        out.append(sb.learning(1e-6, 40, 0.3))
-    a, b = out
-    assert a["status"] == b["status"] and abs(a["em_steps"] - b["em_steps"]) <= 1
-    if a["em_steps"] == b["em_steps"] and a["status"] == 1 and list(a["na"]) == list(b["na"]):
-        assert np.abs(a["cab"] - b["cab"]).max() < 1e-7 * np.abs(a["cab"]).max()
-        assert abs(a["free_energy"] - b["free_energy"]) < 1e-9 * max(1.0, abs(a["free_energy"]))
-        assert abs(a["overlap"] - b["overlap"]) < 1e-9
+    bm = S.blockmodel_t(g, Q, 0)
+    bp = S.bp_basic()
+    bp.init_messages(bm, 0, None, tc, seed)
+    one = bp.learning(bm, S.bp_blockmodel_state(cab0, na), 1e-6, 60, 0.3, 1.0)
+    cab1, na1 = bp.get_params()
+    sb = LocalShards(g, Q, 0, int(rng.integers(2, 5)), n_chunks=int(rng.integers(1, 5)))
+    sb.init_messages(0, None, tc, seed, False)
+    sb.expand_bp_params(cab0, na, 1.0)
+    b = sb.learning(1e-6, 60, 0.3)
+    sb.close()
+    assert abs(one.em_steps - b["em_steps"]) <= 1
+    if one.em_steps == b["em_steps"] and one.status == 1 and b["status"] == 1 and list(na1) == list(b["na"]):
+        assert np.abs(cab1 - b["cab"]).max() < 1e-7 * np.abs(cab1).max()
+        assert abs(one.free_energy - b["free_energy"]) < 1e-9 * max(1.0, abs(one.free_energy))
+        assert abs(one.overlap - b["overlap"]) < 1e-9

@@ -1,6 +1,7 @@
-"""CPU tier for the N>1 path: the sharding plan, the halo exchange and the convergence driver of
-sbm-bp_amd/distributed.py, with a numpy stand-in for the shard kernel (tests/shard_numpy_backend.py).
-Covers in-process lock-step shards (LocalComm) and two real processes over gloo (TorchDistComm)."""
+"""CPU tier for the N>1 path: the shard plan csrc/dist.hip builds (sbmbp_plan_*: host code, no GPU) against its numpy
+restatement (tests/plan_model.py) array for array, its invariants (what p sends is what q expects, slice for slice; cut
+edges line up record for record), and the multi-rank protocol run on that C++ plan with a numpy stand-in for the shard
+kernels (tests/shard_protocol_model.py): ranks in lock-step in one process, and two real processes over gloo."""
 import os
 import subprocess
 import sys
@@ -8,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, args_of, best_perm_diff, golden, gpath
+from conftest import ROOT, args_of, best_perm_diff, golden
 
 
 def _problem(orc, name="c1_matched_tight_seed0"):
@@ -22,127 +23,142 @@ def _problem(orc, name="c1_matched_tight_seed0"):
     return a, r, g, cab, na, psi0, msg0
 
 
-def _sharded(g, a, cab, na, psi0, msg0, world):
-    from sbm_bp_amd.distributed import LocalComm, ShardedBP
+def _graph(g):
+    import sbm_bp_amd as S
+    return S.Graph.from_csr(g.row_ptr, g.nbr, g.rev)
+
+
+def _model(g, a, cab, na, psi0, msg0, world, n_chunks=4):
     from shard_numpy_backend import NumpyShardBackend
-    comm = LocalComm(world)
-    sb = ShardedBP.from_csr(g.row_ptr, g.nbr, a["Q"], a["dc"], comm, backend_factory=lambda p: NumpyShardBackend(p, a["Q"], a["dc"]))
+    from shard_protocol_model import CppPlan, LocalComm, ProtocolModel
+    gg = _graph(g)
+    plans = [CppPlan(gg, world, r, n_chunks if world > 1 else 1) for r in range(world)]
+    sb = ProtocolModel(plans, a["Q"], a["dc"], LocalComm(world), backend_factory=lambda p: NumpyShardBackend(p, a["Q"], a["dc"]))
     for sh in sb.shards:
         sh.init_from_global(psi0, msg0, a["true_conf"])
     sb.expand_bp_params(cab, na, a["beta"])
     return sb
 
 
-def test_partition_and_plan_invariants(orc):
-    from sbm_bp_amd.plan import ShardPlan, partition_rows
-    a, r, g, *_ = _problem(orc)
+@pytest.mark.parametrize("name", ["c1_matched_tight_seed0", "q4_tight_seed0", "hub_dc1_tight_seed0"])
+def test_cpp_plan_equals_the_numpy_restatement(orc, name):
+    from plan_model import ShardPlan, partition_rows
+    from shard_protocol_model import CppPlan
+    a, r, g, *_ = _problem(orc, name)
+    gg = _graph(g)
     for world in (1, 2, 3, 8):
         bounds = partition_rows(g.row_ptr, world)
-        assert bounds[0] == 0 and bounds[-1] == g.N and (np.diff(bounds) > 0).all()
-        plans = [ShardPlan(g.row_ptr, g.nbr, bounds, k, n_chunks=3) for k in range(world)]
+        for rank in range(world):
+            ref = ShardPlan(g.row_ptr, g.nbr, bounds, rank, n_chunks=3)
+            p = CppPlan(gg, world, rank, 3)
+            assert (p.row0, p.n_own, p.n_halo, p.n_edges, p.edge0) == (ref.row0, ref.n_own, ref.n_halo, ref.n_edges, ref.edge0)
+            for f in ("nbr_local", "halo_global", "chunk_row", "send_counts", "recv_counts", "send_counts_cp", "recv_counts_cp",
+                      "send_idx_chunked", "snd_ptr", "snd_slot", "send_off_c", "stage_off_c", "send_off_cp"):
+                assert (np.asarray(getattr(p, f)).astype(np.int64) == np.asarray(getattr(ref, f)).astype(np.int64)).all(), (world, rank, f)
+
+
+def test_plan_invariants_and_cut_edges(orc):
+    from shard_protocol_model import CppPlan
+    a, r, g, *_ = _problem(orc)
+    gg = _graph(g)
+    for world in (1, 2, 3, 8):
+        plans = [CppPlan(gg, world, k, 3) for k in range(world)]
         assert sum(p.n_own for p in plans) == g.N and sum(p.n_edges for p in plans) == g.E2
+        assert plans[0].row0 == 0 and all(plans[k].row0 + plans[k].n_own == plans[k + 1].row0 for k in range(world - 1))
+        w = [p.n_edges + 2 * p.n_own for p in plans]
+        assert max(w) <= 1.2 * (sum(w) / world) + 64  # balanced on sum(deg + 2)
         for p in plans:  # chunked exchange: per (chunk, peer) what p sends is what the peer expects, slice for slice
             assert p.chunk_row[0] == 0 and p.chunk_row[-1] == p.n_own and (np.diff(p.chunk_row.astype(np.int64)) >= 0).all()
-            assert sorted(p.send_idx_chunked.tolist()) == sorted(p.send_idx.tolist())
+            table = np.concatenate([np.arange(p.row0, p.row0 + p.n_own), p.halo_global]).astype(np.int64)
+            assert (table[p.nbr_local] == g.nbr[p.edge0:p.edge0 + p.n_edges]).all()  # every edge reads the right vertex
             for q in plans:
                 for c in range(3):
                     s0, n = int(p.send_off_cp[c, q.rank]), int(p.send_counts_cp[c, q.rank])
-                    sent = p.row0 + p.send_idx_chunked[s0:s0 + n]
-                    assert ((p.row0 + p.chunk_row[c] <= sent) & (sent < p.row0 + p.chunk_row[c + 1])).all()
-                    h0, m = int(q.recv_off_cp[c, p.rank]), int(q.recv_counts_cp[c, p.rank])
+                    sent = p.row0 + p.send_idx_chunked[s0:s0 + n].astype(np.int64)
+                    assert ((p.row0 + int(p.chunk_row[c]) <= sent) & (sent < p.row0 + int(p.chunk_row[c + 1]))).all()
+                    h0 = int(q.stage_off_c[c] + q.recv_counts_cp[c, :p.rank].sum())
+                    m = int(q.recv_counts_cp[c, p.rank])
                     assert m == n and (sent == q.halo_global[h0:h0 + m]).all()
-        w = [p.n_edges + 2 * p.n_own for p in plans]
-        assert max(w) <= 1.2 * (sum(w) / world) + 64
-        for p in plans:
-            assert (p.nbr_local < p.n_own + p.n_halo).all()
-            # the local table entry of every edge is the right global vertex
-            table = np.concatenate([np.arange(p.row0, p.row0 + p.n_own), p.halo_global])
-            assert (table[p.nbr_local] == g.nbr[p.edge0:p.edge0 + p.n_edges]).all()
-            for q in plans:  # what p sends to q is exactly the part of q's halo that p owns (the halo is kept in receive
-                s0 = int(p.send_counts[:q.rank].sum())  # order, (chunk, peer, id): checked slice for slice above)
-                sent = p.row0 + p.send_idx[s0:s0 + int(p.send_counts[q.rank])]
-                owned = q.halo_global[(q.halo_global >= p.row0) & (q.halo_global < p.row0 + p.n_own)]
-                assert sorted(sent.tolist()) == sorted(owned.tolist())
-            # send slots: row i's marginal goes to exactly the slots whose send index is i
             assert p.snd_ptr[-1] == len(p.send_idx_chunked)
-            for i in (0, p.n_own // 2, p.n_own - 1):
+            for i in (0, p.n_own // 2, p.n_own - 1):  # row i's marginal goes to exactly the slots whose send index is i
                 slots = p.snd_slot[p.snd_ptr[i]:p.snd_ptr[i + 1]]
                 assert (p.send_idx_chunked[slots] == i).all() and len(slots) == int((p.send_idx_chunked == i).sum())
+        # message-gather form: rev_local of an own-own edge is the local reverse edge; the records p sends q arrive, in order,
+        # exactly where q's cut edges to p point (the x-th record from p is the reverse message of q's x-th cut edge to p)
+        for p in plans:
+            src = np.repeat(np.arange(p.n_own), p.deg) + p.row0
+            dst = g.nbr[p.edge0:p.edge0 + p.n_edges].astype(np.int64)
+            own = (dst >= p.row0) & (dst < p.row0 + p.n_own)
+            assert (p.rev_local[own].astype(np.int64) == g.rev[p.edge0:p.edge0 + p.n_edges][own].astype(np.int64) - p.edge0).all()
+            assert p.n_halo_msgs == int((~own).sum()) and sorted(p.rev_local[~own].tolist()) == list(range(p.n_edges, p.n_edges + p.n_halo_msgs))
+            off = 0
+            for q in plans:
+                n = int(p.msg_counts[q.rank])
+                assert n == int(q.msg_counts[p.rank])
+                sent = p.msg_send_edge[off:off + n].astype(np.int64)  # p's local edges (i -> l), l owned by q
+                off += n
+                qsrc = np.repeat(np.arange(q.n_own), q.deg) + q.row0
+                qdst = g.nbr[q.edge0:q.edge0 + q.n_edges].astype(np.int64)
+                r0 = q.n_edges + int(q.msg_counts[:p.rank].sum())
+                for x in (0, n // 2, n - 1) if n else ():
+                    k = int(np.flatnonzero(q.rev_local == r0 + x)[0])  # q's edge that gathers record x from p
+                    assert (qsrc[k], qdst[k]) == (dst[sent[x]], src[sent[x]])
 
 
 @pytest.mark.parametrize("world", [2, 3, 5])
-def test_sharded_iterates_equal_unsharded(orc, world):
+def test_protocol_iterates_equal_one_rank(orc, world):
     a, r, g, cab, na, psi0, msg0 = _problem(orc)
-    ref = _sharded(g, a, cab, na, psi0, msg0, 1)
-    sb = _sharded(g, a, cab, na, psi0, msg0, world)
+    ref = _model(g, a, cab, na, psi0, msg0, 1)
+    sb = _model(g, a, cab, na, psi0, msg0, world)
     for _ in range(3):
         d1, dk = ref.sweep(2), sb.sweep(2)
         assert abs(d1 - dk) < 1e-13
-        psi_ref, msg_ref = ref.local_state()[0]
-        psi_k = np.concatenate([s[0] for s in sb.local_state()])
-        msg_k = np.concatenate([s[1] for s in sb.local_state()])
+        psi_ref, msg_ref = ref.shards[0].get_state()
+        psi_k = np.concatenate([sh.get_state()[0] for sh in sb.shards])
+        msg_k = np.concatenate([sh.get_state()[1] for sh in sb.shards])
         assert np.abs(psi_k - psi_ref).max() < 1e-13 and np.abs(msg_k - msg_ref).max() < 1e-13
 
 
 @pytest.mark.parametrize("name", ["c1_matched_tight_seed0", "c1_dc1_tight_seed0", "q4_tight_seed0"])
-def test_sharded_converges_to_reference_fixed_point(orc, name):
+def test_protocol_converges_to_reference_fixed_point(orc, name):
     a, r, g, cab, na, psi0, msg0 = _problem(orc, name)
-    sb = _sharded(g, a, cab, na, psi0, msg0, 3)
+    sb = _model(g, a, cab, na, psi0, msg0, 3)
     niter, exact = sb.converge(1e-12, 3000, 1.0, check_every=5)
     assert niter >= 0 and exact < 1e-12
-    psi = np.concatenate([s[0] for s in sb.local_state()])
+    psi = np.concatenate([sh.get_state()[0] for sh in sb.shards])
     d, _ = best_perm_diff(psi, np.array(r["psi"]).reshape(psi.shape))
     assert d < 1e-9
     assert abs(sb.compute_overlap() - r["overlap"]) < 1e-9
-    one = _sharded(g, a, cab, na, psi0, msg0, 1)
+    one = _model(g, a, cab, na, psi0, msg0, 1)
     assert one.converge(1e-12, 3000, 1.0, check_every=1)[0] == niter  # batching and sharding do not change niter
 
 
 def test_two_processes_over_gloo(orc, tmp_path):
-    """world_size 2, backend gloo: the TorchDistComm path (all_to_all_single + all_reduce)"""
+    """world_size 2, backend gloo: each process builds ITS rank's plan in C++ and the two exchange what the plans say"""
     script = os.path.join(ROOT, "tests", "sharded_gloo_worker.py")
     out = tmp_path / "result.npz"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    from bench import free_port
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", script, str(out)]
+           "--master-port", str(free_port()), script, str(out)]
     subprocess.run(cmd, check=True, env=env, timeout=300, capture_output=True)
     res = np.load(out)
     a, r, g, cab, na, psi0, msg0 = _problem(orc)
-    ref = _sharded(g, a, cab, na, psi0, msg0, 1)
+    ref = _model(g, a, cab, na, psi0, msg0, 1)
     niter, exact = ref.converge(1e-12, 3000, 1.0, check_every=4)
     assert int(res["niter"]) == niter
-    assert np.abs(res["psi"] - ref.local_state()[0][0]).max() < 1e-12
+    assert np.abs(res["psi"] - ref.shards[0].get_state()[0]).max() < 1e-12
     assert abs(float(res["overlap"]) - ref.compute_overlap()) < 1e-12
 
 
-@pytest.mark.parametrize("world,k", [(2, 2), (3, 2), (4, 4)])
-def test_block_cyclic_layout_is_the_same_problem(orc, world, k):
-    """dealing k*world row blocks round robin (plan.block_cyclic_layout) renames the vertices and nothing else: same
-    graph, every shard one contiguous range, and the sharded run lands on the same marginals in the caller's order"""
-    from sbm_bp_amd.distributed import LocalComm, ShardedBP
-    from sbm_bp_amd.plan import block_cyclic_layout, busiest_link_rows, edge_order, permute_csr
-    from shard_numpy_backend import NumpyShardBackend
-    a, r, g, cab, na, psi0, msg0 = _problem(orc)
-    order, bounds, bb = block_cyclic_layout(g.row_ptr, world, k)
-    assert sorted(order.tolist()) == list(range(g.N)) and bounds[0] == 0 and bounds[-1] == g.N
-    rp2, nb2, inv = permute_csr(g.row_ptr, g.nbr, order, bb)
-    eo = edge_order(g.row_ptr, order)
-    assert (np.diff(rp2.astype(np.int64)) == np.diff(g.row_ptr.astype(np.int64))[order]).all()
-    assert (order[nb2] == g.nbr[eo]).all()  # edge for edge the same neighbours under the renaming
-    assert busiest_link_rows(g.row_ptr, g.nbr, world, 1, 0) > 0
-    plain = _sharded(g, a, cab, na, psi0, msg0, world)
-    plain.converge(1e-12, 3000, 1.0)
-    sb = ShardedBP.from_csr(g.row_ptr, g.nbr, a["Q"], a["dc"], LocalComm(world), interleave=k,
-                            backend_factory=lambda p: NumpyShardBackend(p, a["Q"], a["dc"]))
-    assert sb.interleave == k and (sb.order == order).all()
-    for sh in sb.shards:
-        sh.init_from_global(psi0[order], msg0[eo], np.asarray(a["true_conf"])[order])
-    sb.expand_bp_params(cab, na, a["beta"])
-    niter, _ = sb.converge(1e-12, 3000, 1.0)
-    assert niter >= 0
-    psi = sb.to_caller_order(np.concatenate([s[0] for s in sb.local_state()]))
-    assert np.abs(psi - np.concatenate([s[0] for s in plain.local_state()])).max() < 1e-10
-    assert abs(sb.compute_overlap() - plain.compute_overlap()) < 1e-10
-    # the link-load estimate used by interleave="auto" equals what the plan really sends
-    for rk, p in enumerate(sb.plans):
-        assert busiest_link_rows(g.row_ptr, g.nbr, world, k, rk) == int(p.send_counts.max())
+def test_bench_self_launches_its_ranks_dry_run():
+    """`python bench.py --gpus 2` from a bare shell starts its own two ranks (no torchrun): rendezvous, per-rank C++ plans,
+    cross-check of what the ranks will send each other — the part of the N > 1 bench that needs no GPU"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--workload", "small"],
+                        env=env, timeout=300, capture_output=True, text=True)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    line = [l for l in pr.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["dry_run"] and out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["plans_consistent"]
