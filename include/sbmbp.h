@@ -342,6 +342,10 @@ typedef struct sbmbp_comm_callbacks {
 } sbmbp_comm_callbacks;
 int sbmbp_comm_init_callbacks(sbmbp_comm_t **out, int n_ranks, int rank, const sbmbp_comm_callbacks *cb);
 void sbmbp_comm_destroy(sbmbp_comm_t *c);
+/* a rank that gives up (an error outside a collective) tells its peers, so that none of them blocks waiting for it: the
+ * in-process transport fails every later collective of the group (it also times out after SBMBP_LOCAL_TIMEOUT_S, default
+ * 600 s), RCCL communicators are aborted (ncclCommAbort) */
+void sbmbp_comm_abort(sbmbp_comm_t *c);
 int sbmbp_comm_rank(const sbmbp_comm_t *c);
 int sbmbp_comm_size(const sbmbp_comm_t *c);
 const char *sbmbp_comm_transport(const sbmbp_comm_t *c); /* "rccl" | "local" | "callbacks" */

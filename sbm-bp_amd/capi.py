@@ -142,6 +142,7 @@ SYMBOLS = {
     "sbmbp_comm_init_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "sbmbp_comm_init_callbacks": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(CommCallbacks)]),
     "sbmbp_comm_destroy": (None, [C.c_void_p]),
+    "sbmbp_comm_abort": (None, [C.c_void_p]),
     "sbmbp_comm_rank": (C.c_int, [C.c_void_p]),
     "sbmbp_comm_size": (C.c_int, [C.c_void_p]),
     "sbmbp_comm_transport": (C.c_char_p, [C.c_void_p]),

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
@@ -268,7 +269,8 @@ struct local_group {
     std::condition_variable cv;
     int waiting = 0;
     u64 generation = 0;
-    bool failed = false;
+    bool failed = false;  // a rank gave up (error or time-out): every barrier returns false from then on, nobody blocks
+    double timeout_s = 600.0;
     struct slot {
         const double *send = nullptr;
         const u64 *send_counts = nullptr;
@@ -277,13 +279,33 @@ struct local_group {
         std::vector<double> host;  // all-reduce staging
     };
     std::vector<slot> slots;
-    void barrier() {
+    bool barrier() {
         std::unique_lock<std::mutex> lk(mu);
+        if (failed) return false;
         const u64 gen = generation;
         if (++waiting == n) { waiting = 0; ++generation; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != gen; });
+        else if (!cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return generation != gen || failed; })) {
+            failed = true;  // a peer never arrived (it failed outside a collective, or the ranks' call sequences differ)
+            cv.notify_all();
+        }
+        return !failed;
+    }
+    void fail() {
+        std::lock_guard<std::mutex> lk(mu);
+        failed = true;
+        cv.notify_all();
     }
 };
+#define LOCAL_BARRIER(g)                                                                    \
+    do {                                                                                    \
+        if (!(g).barrier()) { set_error("a peer rank failed or timed out"); return SBMBP_ERR_COMM; } \
+    } while (0)
+// a HIP error between two barriers must not leave the peers waiting
+#define LOCAL_HIP(g, call)                                                                  \
+    do {                                                                                    \
+        hipError_t _e = (call);                                                             \
+        if (_e != hipSuccess) { (g).fail(); set_error(std::string(#call) + ": " + hipGetErrorString(_e)); return SBMBP_ERR_HIP; } \
+    } while (0)
 
 }  // namespace
 
@@ -337,28 +359,30 @@ int comm_exchange(sbmbp_comm *c, const double *send, const u64 *send_counts, dou
         me.send = send;
         me.send_counts = send_counts;
         me.width = width;
-        HIPCHK(hipEventRecord(me.ready, stream));  // my send rows are final behind this point of my stream
-        g.barrier();
+        LOCAL_HIP(g, hipEventRecord(me.ready, stream));  // my send rows are final behind this point of my stream
+        LOCAL_BARRIER(g);
         u64 ro = 0;
         for (int p = 0; p < W; ++p) {  // pull what every peer has for me
             if (recv_counts[p]) {
                 const local_group::slot &pe = g.slots[p];
                 u64 so = 0;
                 for (int q = 0; q < c->rank; ++q) so += pe.send_counts[q];
-                if (pe.send_counts[c->rank] != recv_counts[p]) { set_error("exchange counts of two ranks disagree"); g.failed = true; }
-                else {
-                    HIPCHK(hipStreamWaitEvent(stream, pe.ready, 0));
-                    HIPCHK(hipMemcpyAsync(recv + ro * width, pe.send + so * width, recv_counts[p] * width * 8, hipMemcpyDeviceToDevice, stream));
+                if (pe.send_counts[c->rank] != recv_counts[p] || pe.width != width) {
+                    g.fail();
+                    set_error("exchange counts of two ranks disagree");
+                    return SBMBP_ERR_COMM;
                 }
+                LOCAL_HIP(g, hipStreamWaitEvent(stream, pe.ready, 0));
+                LOCAL_HIP(g, hipMemcpyAsync(recv + ro * width, pe.send + so * width, recv_counts[p] * width * 8, hipMemcpyDeviceToDevice, stream));
             }
             ro += recv_counts[p];
         }
-        HIPCHK(hipEventRecord(me.done, stream));  // my reads of the peers' send rows end here
-        g.barrier();
+        LOCAL_HIP(g, hipEventRecord(me.done, stream));  // my reads of the peers' send rows end here
+        LOCAL_BARRIER(g);
         for (int p = 0; p < W; ++p)  // a peer that read my rows must be through before later work on my stream rewrites them
-            if (send_counts[p]) HIPCHK(hipStreamWaitEvent(stream, g.slots[p].done, 0));
-        g.barrier();  // nobody re-records an event a peer has not consumed yet
-        return g.failed ? SBMBP_ERR_COMM : SBMBP_OK;
+            if (send_counts[p]) LOCAL_HIP(g, hipStreamWaitEvent(stream, g.slots[p].done, 0));
+        LOCAL_BARRIER(g);  // nobody re-records an event a peer has not consumed yet
+        return SBMBP_OK;
     }
     const u64 ns = sum_counts(send_counts, W), nr = sum_counts(recv_counts, W);
     CHK(ensure_host(c, std::max<u64>(1, std::max(ns, nr) * width)));
@@ -379,16 +403,16 @@ int comm_allgather(sbmbp_comm *c, const double *in, size_t n, double *out, hipSt
         local_group &g = *c->grp;
         local_group::slot &me = g.slots[c->rank];
         me.send = in;
-        HIPCHK(hipEventRecord(me.ready, stream));
-        g.barrier();
+        LOCAL_HIP(g, hipEventRecord(me.ready, stream));
+        LOCAL_BARRIER(g);
         for (int p = 0; p < W; ++p) {
-            if (p != c->rank) HIPCHK(hipStreamWaitEvent(stream, g.slots[p].ready, 0));
-            HIPCHK(hipMemcpyAsync(out + size_t(p) * n, g.slots[p].send, n * 8, hipMemcpyDeviceToDevice, stream));
+            if (p != c->rank) LOCAL_HIP(g, hipStreamWaitEvent(stream, g.slots[p].ready, 0));
+            LOCAL_HIP(g, hipMemcpyAsync(out + size_t(p) * n, g.slots[p].send, n * 8, hipMemcpyDeviceToDevice, stream));
         }
-        HIPCHK(hipEventRecord(me.done, stream));
-        g.barrier();
-        for (int p = 0; p < W; ++p) if (p != c->rank) HIPCHK(hipStreamWaitEvent(stream, g.slots[p].done, 0));
-        g.barrier();
+        LOCAL_HIP(g, hipEventRecord(me.done, stream));
+        LOCAL_BARRIER(g);
+        for (int p = 0; p < W; ++p) if (p != c->rank) LOCAL_HIP(g, hipStreamWaitEvent(stream, g.slots[p].done, 0));
+        LOCAL_BARRIER(g);
         return SBMBP_OK;
     }
     CHK(ensure_host(c, std::max<size_t>(1, n * W)));
@@ -409,18 +433,20 @@ int comm_allreduce(sbmbp_comm *c, double *buf, size_t n, int op, hipStream_t str
         local_group &g = *c->grp;
         local_group::slot &me = g.slots[c->rank];
         me.host.resize(n);
-        HIPCHK(hipMemcpyAsync(me.host.data(), buf, n * 8, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
-        g.barrier();
+        LOCAL_HIP(g, hipMemcpyAsync(me.host.data(), buf, n * 8, hipMemcpyDeviceToHost, stream));
+        LOCAL_HIP(g, hipStreamSynchronize(stream));
+        LOCAL_BARRIER(g);
         std::vector<double> acc(g.slots[0].host);
-        for (int p = 1; p < W; ++p)
+        for (int p = 1; p < W; ++p) {
+            if (g.slots[p].host.size() != n) { g.fail(); set_error("all-reduce sizes of two ranks disagree"); return SBMBP_ERR_COMM; }
             for (size_t i = 0; i < n; ++i) {
                 const double v = g.slots[p].host[i];
                 acc[i] = op == 0 ? acc[i] + v : ((v > acc[i] || v != v) ? v : acc[i]);
             }
-        g.barrier();  // everybody has read the staged vectors
-        HIPCHK(hipMemcpyAsync(buf, acc.data(), n * 8, hipMemcpyHostToDevice, stream));
-        HIPCHK(hipStreamSynchronize(stream));  // acc is a local
+        }
+        LOCAL_BARRIER(g);  // everybody has read the staged vectors
+        LOCAL_HIP(g, hipMemcpyAsync(buf, acc.data(), n * 8, hipMemcpyHostToDevice, stream));
+        LOCAL_HIP(g, hipStreamSynchronize(stream));  // acc is a local
         return SBMBP_OK;
     }
     CHK(ensure_host(c, n));
@@ -475,6 +501,7 @@ int sbmbp_comm_init_local(sbmbp_comm_t **out, int n_ranks) {
     if (!out || n_ranks < 1) return SBMBP_ERR_ARG;
     auto g = std::make_shared<local_group>();
     g->n = n_ranks;
+    if (const char *t = std::getenv("SBMBP_LOCAL_TIMEOUT_S")) g->timeout_s = std::max(1.0, std::atof(t));
     g->slots.resize(n_ranks);
     for (int r = 0; r < n_ranks; ++r) {
         auto *c = new sbmbp_comm();
@@ -511,6 +538,16 @@ void sbmbp_comm_destroy(sbmbp_comm_t *c) {
     if (c->h_a) (void)hipHostFree(c->h_a);
     if (c->h_b) (void)hipHostFree(c->h_b);
     delete c;
+}
+
+// a rank that gives up tells the others, so that none of them blocks in a collective waiting for it
+void sbmbp_comm_abort(sbmbp_comm_t *c) {
+    if (!c) return;
+    if (c->kind == 1 && c->grp) c->grp->fail();
+    if (c->kind == 0) {
+        if (c->halo) { ncclCommAbort(c->halo); c->halo = nullptr; }
+        if (c->red) { ncclCommAbort(c->red); c->red = nullptr; }
+    }
 }
 
 int sbmbp_comm_rank(const sbmbp_comm_t *c) { return c ? c->rank : -1; }
@@ -595,8 +632,9 @@ int refresh_marginal_halo(sbmbp_dist *d, u32 j) {
 // records of the cut edges of the message buffer sweep j reads -> behind the own records of that buffer on the peers
 int refresh_message_halo(sbmbp_dist *d, u32 j) {
     const shard_plan &P = d->plan;
-    if (d->world == 1 || P.n_halo_msgs == 0) return SBMBP_OK;
-    CHK(sbmbp_shard_pack_msgs(d->eng, j, d->d_msg_send_edge, u32(P.n_halo_msgs), d->d_msg_send));
+    if (d->world == 1) return SBMBP_OK;
+    // (a rank without cut edges still takes part: a collective is a collective for every rank of the communicator)
+    if (P.n_halo_msgs) CHK(sbmbp_shard_pack_msgs(d->eng, j, d->d_msg_send_edge, u32(P.n_halo_msgs), d->d_msg_send));
     CHK(ship(d, d->d_msg_send, P.msg_counts.data(), static_cast<double *>(sbmbp_shard_msg_halo(d->eng, j)), P.msg_counts.data(), int(d->Q) - 1,
              d->ev_a, d->ev_b));
     HIPCHK(hipStreamWaitEvent(d->s_compute, d->ev_b, 0));
@@ -925,16 +963,17 @@ int sbmbp_dist_create(sbmbp_dist_t **out, sbmbp_comm_t *comm, const sbmbp_graph_
     desc.row0 = P.row0;
     desc.n_edges = P.n_edges;
     desc.edge0 = P.edge0;
+    static const u32 none32 = 0;  // an empty shard still HAS these arrays (a null pointer means "not provided")
     desc.row_ptr = P.row_ptr.data();
-    desc.nbr_local = P.nbr_local.data();
+    desc.nbr_local = P.nbr_local.empty() ? &none32 : P.nbr_local.data();
     desc.psi_buf0 = d->d_psi[0];
     desc.psi_buf1 = d->d_psi[1];
     desc.red_buf = d->d_red;
     desc.n_chunks = P.n_chunks;
     desc.chunk_row = P.chunk_row.data();
-    desc.rev_local = P.rev_local.data();
+    desc.rev_local = P.rev_local.empty() ? &none32 : P.rev_local.data();
     desc.n_halo_msgs = P.n_halo_msgs;
-    desc.table_deg = P.table_deg.data();
+    desc.table_deg = P.table_deg.empty() ? &none32 : P.table_deg.data();
     CHK(sbmbp_shard_create(&d->eng, &desc, Q, dc, d->device));
     HIPCHK(hipStreamCreateWithFlags(&d->s_compute, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&d->s_comm, hipStreamNonBlocking));

@@ -12,7 +12,7 @@ One rank = one GPU = one `ShardedBP`. The plan (vertex ranges, halo, send lists,
 No reference counterpart: junipertcy/sbm-bp is single-process.
 """
 import ctypes as C
-from concurrent.futures import ThreadPoolExecutor
+from concurrent.futures import FIRST_EXCEPTION, ThreadPoolExecutor, wait
 
 import numpy as np
 
@@ -40,6 +40,9 @@ class Comm:
             self._lib.sbmbp_comm_destroy(self._h)
         except Exception:
             pass
+
+    def abort(self):
+        self._lib.sbmbp_comm_abort(self._h)
 
     @classmethod
     def rccl_from_torch(cls, device):
@@ -306,6 +309,15 @@ class LocalShards:
 
     def _all(self, fn, by_index=False):
         futs = [self._pools[r].submit(fn, r if by_index else self.ranks[r]) for r in range(self.world)]
+        done, _ = wait(futs, return_when=FIRST_EXCEPTION)
+        if any(f.exception() is not None for f in done):  # one rank gave up: wake the others out of their collectives
+            for c in self.comms:
+                c.abort()
+        errs = [f.exception() for f in futs]  # (waits for all)
+        # report the rank that failed, not a peer that was woken out of a collective because of it
+        first = next((e for e in errs if e is not None and getattr(e, "code", 0) != -8), None) or next((e for e in errs if e is not None), None)
+        if first is not None:
+            raise first
         return [f.result() for f in futs]
 
     def close(self):

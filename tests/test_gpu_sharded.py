@@ -214,7 +214,7 @@ def test_message_gather_modes_on_shards(S, orc):
     """everything the marginal-gather form cannot do runs sharded through the message-gather form (cut-edge messages shipped
     every sweep): damping, clamped rows (-i 1), deg_corr_flag 2, a zero in cab. Same iterates as the single engine."""
     from sbm_bp_amd.distributed import LocalShards
-    cases = [("c1_matched_damped_seed0", {}), ("c1_planted_i1_seed0", {}), ("c1_dc2_tight_seed0", {}), ("c1_matched_tight_seed0", {"zero": True})]
+    cases = [("c1_matched_damped_seed0", {}), ("c1_planted_i1_seed0", {}), ("c1_dc2_tight_seed0", {}), ("q4_tight_seed0", {"zero": True})]
     for name, opt in cases:
         gd = golden(name)
         a = args_of(gd)
@@ -242,7 +242,7 @@ def test_message_gather_modes_on_shards(S, orc):
             assert np.abs(pk - p1).max() < 1e-12 and np.abs(mk - m1).max() < 1e-12, name
         n1, l1 = bp.converge(1e-10, 3000, a["damp"])
         nk, lk = sb.converge(1e-10, 3000, a["damp"])
-        assert n1 == nk and n1 >= 0, name
+        assert n1 == nk and (n1 >= 0 or opt.get("zero")), name
         f1, fk = bp.compute_free_energy(parts=True)[1], sb.compute_free_energy(parts=True)[1]
         assert np.abs(f1 - fk).max() < 1e-10 * max(1.0, np.abs(f1).max()), name
         e1, ek = bp.em_expectations(), sb.em_expectations()
