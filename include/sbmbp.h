@@ -50,6 +50,7 @@ typedef struct sbmbp_engine sbmbp_engine_t; /* device engine (one GPU) */
 const char *sbmbp_strerror(int code);
 const char *sbmbp_last_error(void); /* thread-local detail string of the last failure */
 const char *sbmbp_version(void);
+int sbmbp_device_count(void); /* GPUs visible to this process (0 if none) */
 
 /* ---------------------------------------------------------------------------------------------
  * Graph input. Replaces load_edge_list + edge_to_adj (graph_utilities.cpp:42-77: text "a b" per

@@ -68,6 +68,7 @@ SYMBOLS = {
     "sbmbp_strerror": (C.c_char_p, [C.c_int]),
     "sbmbp_last_error": (C.c_char_p, []),
     "sbmbp_version": (C.c_char_p, []),
+    "sbmbp_device_count": (C.c_int, []),
     "sbmbp_graph_load_edgelist": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_uint32]),
     "sbmbp_graph_from_edges": (C.c_int, [C.POINTER(C.c_void_p), c_u32p, C.c_uint64, C.c_uint32]),
     "sbmbp_graph_from_csr": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint64, c_u64p, c_u32p, c_u32p]),

@@ -3,7 +3,9 @@
 // main.cpp:85-365, without Boost; all BP work goes through the C ABI of include/sbmbp.h.
 // Host code is C++14. Flags the reference parses but never reads (main.cpp:126-135)
 // are accepted and ignored. Extensions (default off, stdout unchanged): --precision, --device,
-// --gather, --field_mix, --check_every, --metrics_json.
+// --gather, --field_mix, --check_every, --metrics_json, and --gpus N: the graph is sharded by vertex range over N GPUs of
+// this node, one host thread per GPU driving the C++ multi-GPU driver (sbmbp_dist_*, RCCL over xGMI); with fewer devices
+// than ranks the ranks share devices over the in-process transport (a rehearsal, not a speed-up).
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -16,6 +18,7 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sbmbp.h"
@@ -32,6 +35,7 @@ const opt_spec OPTS[] = {
     {"pa", 0, 2}, {"cab", 0, 2}, {"if_output_marginals", 0, 0}, {"mode", 'm', 1}, {"seed", 'd', 1}, {"help", 'h', 0},
     // extensions
     {"precision", 0, 1}, {"device", 0, 1}, {"gather", 0, 1}, {"field_mix", 0, 1}, {"check_every", 0, 1}, {"metrics_json", 0, 1},
+    {"gpus", 0, 1}, {"transport", 0, 1},
 };
 
 const opt_spec *find_long(const std::string &name) {
@@ -146,7 +150,9 @@ void usage(const char *argv0) {
                  "  -h [ --help ]                         Produce this help message.\n"
                  "MI355X engine extensions:\n"
                  "  --precision arg (=6)  --device arg (=0)  --gather auto|messages  --field_mix arg (=1)\n"
-                 "  --check_every arg (=8)  --metrics_json path\n";
+                 "  --check_every arg (=8)  --metrics_json path\n"
+                 "  --gpus arg (=1)       shard the graph by vertex range over this many GPUs (one host thread each, RCCL)\n"
+                 "  --transport rccl|local  (default rccl; local = ranks may share devices, rehearsal)\n";
 }
 
 bool read_column(const std::string &path, std::vector<long long> &out) {  // load_beliefs/load_confs (graph_utilities.cpp:8-40)
@@ -297,11 +303,6 @@ int main(int argc, char const *argv[]) {
     if (mode != "infer" && mode != "learn") return 0;  // the reference silently does nothing (:361-365)
     stage("read + index graph");
 
-    sbmbp_engine_t *eng = nullptr;
-    rc = sbmbp_create(&eng, graph, Q, deg_corr_flag, int(num("device", 0)));
-    if (rc != SBMBP_OK) return fail(rc);
-    stage("create engine (device)");
-
     std::vector<int32_t> beliefs;  // :325-336
     if (var_map.count("beliefs_path")) {
         std::vector<long long> col;
@@ -312,22 +313,128 @@ int main(int argc, char const *argv[]) {
         for (auto vtx : fixed_nodes) if (vtx < beliefs.size()) beliefs[vtx] = int32_t(true_conf[vtx]);
     }
     if (bp_messages_init_flag != 0 && beliefs.size() != N) { std::clog << "bp: the beliefs vector needs " << N << " entries (-1 = unknown)\n"; return 1; }
-    rc = sbmbp_init_messages(eng, bp_messages_init_flag, beliefs.size() == N ? beliefs.data() : nullptr, true_conf.data(), seed,
-                             mode == "learn" ? 0 : 1);  // bp_basic for learn, bp_conditional otherwise (:318-323)
-    if (rc != SBMBP_OK) return fail(rc);
-    stage("initial state + upload");
-
     std::vector<double> cab_full(size_t(Q) * Q);
     std::vector<uint32_t> na(Q);
     if (bm_params_string == "cab_ec") rc = sbmbp_param_from_epsilon_c(N, Q, epsilon_c[0], epsilon_c[1], cab_full.data(), na.data());
     else rc = sbmbp_param_from_direct(N, Q, pa.data(), cab.data(), cab_full.data(), na.data());
     if (rc != SBMBP_OK) return fail(rc);
+    std::cout << std::setprecision(int(num("precision", 6)));
+    std::clog << std::setprecision(int(num("precision", 6)));
+
+    const int n_gpus = int(num("gpus", 1));
+    if (n_gpus > 1) {
+        // ---- multi-GPU: one host thread per rank, all ranks make the same calls (include/sbmbp.h, "Multi-GPU") ----------
+        const int n_dev = sbmbp_device_count();
+        if (n_dev <= 0) return fail(SBMBP_ERR_NODEVICE);
+        bool local = var_map.count("transport") && var_map.get("transport")[0] == "local";
+        if (n_dev < n_gpus && !local) {
+            std::clog << "bp: --gpus " << n_gpus << " on " << n_dev << " device(s): ranks share devices over the in-process transport (rehearsal)\n";
+            local = true;
+        }
+        std::vector<sbmbp_comm_t *> comms(n_gpus, nullptr);
+        unsigned char comm_id[SBMBP_COMM_ID_BYTES];
+        if (local) rc = sbmbp_comm_init_local(comms.data(), n_gpus);
+        else rc = sbmbp_comm_unique_id(comm_id);
+        if (rc != SBMBP_OK) return fail(rc);
+        std::vector<int> rcs(n_gpus, SBMBP_OK);
+        std::vector<std::string> errs(n_gpus);
+        sbmbp_infer_result ires{};
+        sbmbp_learn_result lres{};
+        std::vector<double> psi_all;
+        std::vector<double> cab_out(cab_full);
+        std::vector<uint32_t> na_out(na);
+        sbmbp_stats st0{};
+        const auto t0 = std::chrono::steady_clock::now();
+        auto rank_main = [&](int r) {
+            const int dev = r % n_dev;
+            sbmbp_dist_t *d = nullptr;
+            int e = SBMBP_OK;
+            auto step = [&](int code) { if (e == SBMBP_OK && code != SBMBP_OK) { e = code; errs[r] = sbmbp_last_error(); } return e == SBMBP_OK; };
+            if (!local) step(sbmbp_comm_init_rank(&comms[r], comm_id, n_gpus, r, dev));
+            if (e == SBMBP_OK) step(sbmbp_dist_create(&d, comms[r], graph, Q, deg_corr_flag, dev, 0));
+            if (e == SBMBP_OK) step(sbmbp_dist_init_messages(d, bp_messages_init_flag, beliefs.size() == N ? beliefs.data() : nullptr, true_conf.data(),
+                                                             seed, mode == "learn" ? 0 : 1));
+            if (e == SBMBP_OK) step(sbmbp_dist_set_params(d, cab_full.data(), na.data(), beta));
+            if (e == SBMBP_OK) step(sbmbp_dist_set_schedule(d, num("field_mix", 1.0), unsigned(num("check_every", 8))));
+            if (e == SBMBP_OK && var_map.count("gather") && var_map.get("gather")[0] == "messages") step(sbmbp_dist_set_gather_mode(d, 1));
+            if (e == SBMBP_OK && mode == "infer") {
+                sbmbp_infer_result res{};
+                if (step(sbmbp_dist_inference(d, bp_conv_crit, time_conv, dumping_rate, &res)) && r == 0) ires = res;
+                if (e == SBMBP_OK && if_output_marginals) {
+                    std::vector<double> all(size_t(N) * Q);
+                    if (step(sbmbp_dist_gather_marginals(d, all.data())) && r == 0) psi_all.swap(all);
+                }
+            } else if (e == SBMBP_OK) {
+                sbmbp_learn_result res{};
+                if (step(sbmbp_dist_learning(d, learning_conv_crit, time_conv, learning_rate, dumping_rate, &res)) && r == 0) {
+                    lres = res;
+                    step(sbmbp_dist_get_params(d, cab_out.data(), na_out.data()));
+                }
+            }
+            if (e == SBMBP_OK && r == 0) step(sbmbp_dist_get_stats(d, &st0));
+            if (e != SBMBP_OK && comms[r]) sbmbp_comm_abort(comms[r]);  // nobody waits for a rank that gave up
+            if (d) sbmbp_dist_destroy(d);
+            rcs[r] = e;
+        };
+        std::vector<std::thread> threads;
+        for (int r = 0; r < n_gpus; ++r) threads.emplace_back(rank_main, r);
+        for (auto &t : threads) t.join();
+        for (auto *c : comms) if (c) sbmbp_comm_destroy(c);
+        for (int r = 0; r < n_gpus; ++r)
+            if (rcs[r] != SBMBP_OK && rcs[r] != SBMBP_ERR_COMM) { std::clog << "bp: rank " << r << ": " << sbmbp_strerror(rcs[r]) << ": " << errs[r] << "\n"; return 1; }
+        for (int r = 0; r < n_gpus; ++r)
+            if (rcs[r] != SBMBP_OK) { std::clog << "bp: rank " << r << ": " << sbmbp_strerror(rcs[r]) << ": " << errs[r] << "\n"; return 1; }
+        if (mode == "infer") {
+            std::cout << signed_nan_like_reference(ires.entropy) << " " << signed_nan_like_reference(ires.free_energy) << " " << ires.overlap << " "
+                      << ires.niter << " \n";
+            if (if_output_marginals) {
+                for (unsigned v = 0; v < N; ++v) {
+                    for (unsigned q = 0; q < Q; ++q) std::cout << psi_all[size_t(v) * Q + q] << " ";
+                    std::cout << "\n";
+                }
+                for (unsigned v = 0; v < N; ++v) {
+                    double h = 0.0;
+                    for (unsigned q = 0; q < Q; ++q) { const double p = psi_all[size_t(v) * Q + q]; if (p > 0) h -= p * std::log(p); }
+                    std::clog << "Node-" << v << "; margEntropy H(v) is " << h << "\n";
+                }
+            }
+        } else {
+            if (lres.status == 2) std::clog << "Bethe energy is calculated as nan.\n";
+            if (lres.status == 1) std::clog << "Algorithm stop because of fdiff < learning_conv_crit. [which is good]\n";
+            for (unsigned q = 0; q < Q; ++q) std::cout << double(na_out[q]) / N << " ";
+            std::cout << "\n";
+            for (unsigned r = 0; r < Q; ++r) {
+                for (unsigned s2 = 0; s2 < Q; ++s2) std::cout << cab_out[size_t(r) * Q + s2] << " ";
+                std::cout << "\n";
+            }
+            std::clog << "overlap:" << lres.overlap << "\n";
+        }
+        stage(mode == "infer" ? "inference (all ranks)" : "learning (all ranks)");
+        if (var_map.count("metrics_json")) {
+            const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::ofstream mj(var_map.get("metrics_json")[0].c_str());
+            mj << std::setprecision(12) << "{\"gpus\":" << n_gpus << ",\"transport\":\"" << (local ? "local" : "rccl") << "\",\"sweeps\":" << st0.sweeps
+               << ",\"edge_msg_updates\":" << st0.edge_msg_updates << ",\"marginal_gather_sweeps\":" << st0.psi_form_sweeps
+               << ",\"run_seconds\":" << secs << "}\n";
+        }
+        sbmbp_graph_destroy(graph);
+        return 0;
+    }
+
+    sbmbp_engine_t *eng = nullptr;
+    rc = sbmbp_create(&eng, graph, Q, deg_corr_flag, int(num("device", 0)));
+    if (rc != SBMBP_OK) return fail(rc);
+    stage("create engine (device)");
+
+    rc = sbmbp_init_messages(eng, bp_messages_init_flag, beliefs.size() == N ? beliefs.data() : nullptr, true_conf.data(), seed,
+                             mode == "learn" ? 0 : 1);  // bp_basic for learn, bp_conditional otherwise (:318-323)
+    if (rc != SBMBP_OK) return fail(rc);
+    stage("initial state + upload");
+
     if ((rc = sbmbp_set_params(eng, cab_full.data(), na.data(), beta)) != SBMBP_OK) return fail(rc);
     if ((rc = sbmbp_set_schedule(eng, num("field_mix", 1.0), unsigned(num("check_every", 8)))) != SBMBP_OK) return fail(rc);
     if (var_map.count("gather") && var_map.get("gather")[0] == "messages") sbmbp_set_gather_mode(eng, 1);
 
-    std::cout << std::setprecision(int(num("precision", 6)));
-    std::clog << std::setprecision(int(num("precision", 6)));
     const auto t0 = std::chrono::steady_clock::now();
     if (mode == "infer") {  // belief_propagation::inference (bp.cpp:77-99)
         sbmbp_infer_result res;

@@ -751,7 +751,11 @@ const char *sbmbp_strerror(int code) {
     }
 }
 const char *sbmbp_last_error(void) { return get_error().c_str(); }
-const char *sbmbp_version(void) { return "sbmbp-hip 0.1 (gfx950)"; }
+const char *sbmbp_version(void) { return "sbmbp-hip 0.2 (gfx950)"; }
+int sbmbp_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 
 int sbmbp_graph_load_edgelist(sbmbp_graph_t **out, const char *path, uint32_t n_vertices) {
     if (!out || !path) return SBMBP_ERR_ARG;

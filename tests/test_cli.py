@@ -194,3 +194,36 @@ def test_vertex_id_beyond_n_is_rejected(tmp_path):
     p.write_text("0 1\n2 12\n")
     rc, out, err = run("-l", p, "-n", 5, 5, "--epsilon_c", 0.1, 3, "-m", "infer")
     assert rc == 1 and out == "" and "vertex ids >= sum(n) = 10" in err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["-R", 0.5], ["-i", 1, "--beliefs_path", gpath("c1_beliefs.txt")]])
+def test_gpus_flag_shards_the_run_and_prints_the_same_lines(extra):
+    """--gpus N: one host thread per rank over the C++ multi-GPU driver. On a one-GPU box the ranks share the device
+    (in-process transport; a note on stderr says so); stdout is the single-GPU run's, digit for digit at 12 places."""
+    args = MATCHED[:-2] + ["--precision", 12, "-e", 1e-12] + extra
+    rc1, out1, err1 = run(*args)
+    rc3, out3, err3 = run(*args, "--gpus", 3)
+    assert rc1 == 0 and rc3 == 0, err3
+    assert "ranks share devices over the in-process transport" in err3 or "--gpus" not in err3
+    e1, f1, o1, n1 = _line(out1)
+    e3, f3, o3, n3 = _line(out3)
+    assert n1 == n3 and abs(f1 - f3) < 1e-11 and abs(e1 - e3) < 1e-11 and abs(o1 - o3) < 1e-11
+
+
+@pytest.mark.gpu
+def test_gpus_flag_learn_and_marginals():
+    rc1, out1, _ = run("-l", DS, "-n", 500, 500, "--pa", 0.5, 0.5, "--cab", 5, 1, 5, "-t", 1000, "-i", 0, "-m", "learn", "-d", 0, "--precision", 9)
+    rc2, out2, err2 = run("-l", DS, "-n", 500, 500, "--pa", 0.5, 0.5, "--cab", 5, 1, 5, "-t", 1000, "-i", 0, "-m", "learn", "-d", 0, "--precision", 9,
+                          "--gpus", 2)
+    assert rc1 == 0 and rc2 == 0, err2
+    a = np.array([float(x) for x in out1.split()])
+    b = np.array([float(x) for x in out2.split()])
+    assert a.shape == b.shape == (6,) and np.abs(a - b).max() < 1e-7 and "overlap:" in err2
+    rc, out, err = run(*MATCHED, "-e", 1e-13, "--if_output_marginals", "--gpus", 4)
+    assert rc == 0
+    lines = out.split("\n")
+    g = golden("c1_matched_tight_seed0")["result"]
+    psi = np.array([[float(x) for x in l.split()] for l in lines[1:1001]])
+    ref = np.array(g["psi"]).reshape(1000, 2)
+    assert min(np.abs(psi - ref).max(), np.abs(psi[:, ::-1] - ref).max()) < 1e-9 and err.count("margEntropy H(v) is") == 1000
