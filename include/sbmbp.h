@@ -215,7 +215,8 @@ typedef struct sbmbp_shard_desc {
     const uint64_t *row_ptr;    /* host [n_own+1], local offsets */
     const uint32_t *nbr_local;  /* host [n_edges]: index into the marginal table: own < n_own <= halo */
     void *psi_buf0, *psi_buf1;  /* device, (n_own+n_halo)*Q doubles each */
-    void *red_buf;              /* device, >= 8192 doubles: reduction hand-off buffer */
+    void *red_buf;              /* device, >= SBMBP_RED_GATHER_OFFSET + n_ranks * SBMBP_FOLD_ROWS * (SBMBP_MAX_Q + 1) doubles (and >= 8192):
+                                   reduction hand-off buffer */
     uint32_t n_chunks;          /* row chunks for overlapping the halo exchange with the sweep (0 or 1 = none) */
     const uint32_t *chunk_row;  /* host [n_chunks+1] local row boundaries, chunk_row[0] = 0, last = n_own */
     /* optional: what the message-gather sweep needs on a shard (any damping, clamped rows, deg_corr_flag 2, zeros in cab) */
@@ -276,11 +277,16 @@ int sbmbp_shard_read_buffer(sbmbp_engine_t *e, uint32_t j);
 int sbmbp_shard_field_partial(sbmbp_engine_t *e, uint32_t j);
 /* sweep j over the owned rows; red[0..Q) = partial sums of the new marginals, red[Q] = hint */
 int sbmbp_shard_sweep_partial(sbmbp_engine_t *e, uint32_t j);
-/* the same in pieces: sweep j over row chunk c only (the caller ships chunk c's new marginals while
- * chunk c+1 runs), then one fold of all chunks' partials into red */
+/* the same in pieces: sweep j over row chunk c only (the caller ships chunk c's new marginals while chunk c+1 runs), then
+ * ONE fold launch of all chunks' partials into SBMBP_FOLD_ROWS rows at red[0..): the caller all-gathers those rows of every
+ * rank behind red + SBMBP_RED_GATHER_OFFSET and sbmbp_shard_finalize folds them (n_rows = n_ranks * SBMBP_FOLD_ROWS) */
 int sbmbp_shard_sweep_chunk(sbmbp_engine_t *e, uint32_t j, uint32_t c);
+/* the same on another HIP stream of the engine's device (the caller orders it against the engine's stream with events):
+ * consecutive chunks on alternating streams overlap each other's tail */
+int sbmbp_shard_sweep_chunk_on(sbmbp_engine_t *e, uint32_t j, uint32_t c, void *hip_stream);
 int sbmbp_shard_sweep_fold(sbmbp_engine_t *e);
-#define SBMBP_RED_GATHER_OFFSET 32 /* > SBMBP_MAX_Q: the gathered rows never overlap the shard's own red[0..Q] */
+#define SBMBP_FOLD_ROWS 64          /* rows of (Q+1) doubles sbmbp_shard_sweep_fold leaves at red[0..) */
+#define SBMBP_RED_GATHER_OFFSET 2048 /* > SBMBP_FOLD_ROWS * (SBMBP_MAX_Q + 1): gathered rows never overlap a shard's own rows */
 /* consume the reduction values: n_rows rows of (Q+1) doubles starting at red + SBMBP_RED_GATHER_OFFSET (the caller
  * all-gathers every shard's red[0..Q] there; n_rows = number of shards). Rows are folded in order —
  * sums for the Q field entries, max for the hint. mode 0 after a sweep, 1 field initialisation */
@@ -342,6 +348,9 @@ typedef struct sbmbp_comm_callbacks {
     int (*allreduce)(void *user, double *buf, uint64_t n, int op /* 0 sum, 1 max */);
 } sbmbp_comm_callbacks;
 int sbmbp_comm_init_callbacks(sbmbp_comm_t **out, int n_ranks, int rank, const sbmbp_comm_callbacks *cb);
+/* measurement only: rank `rank` of an n-rank plan alone on the GPU; exchanges deliver nothing, every peer "reports" this
+ * rank's reduction values (tools/shard_budget.py: what one rank of the 8-GPU run executes per sweep) */
+int sbmbp_comm_init_null(sbmbp_comm_t **out, int n_ranks, int rank);
 void sbmbp_comm_destroy(sbmbp_comm_t *c);
 /* a rank that gives up (an error outside a collective) tells its peers, so that none of them blocks waiting for it: the
  * in-process transport fails every later collective of the group (it also times out after SBMBP_LOCAL_TIMEOUT_S, default

@@ -125,6 +125,7 @@ SYMBOLS = {
     "sbmbp_shard_field_partial": (C.c_int, [C.c_void_p, C.c_uint32]),
     "sbmbp_shard_sweep_partial": (C.c_int, [C.c_void_p, C.c_uint32]),
     "sbmbp_shard_sweep_chunk": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "sbmbp_shard_sweep_chunk_on": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "sbmbp_shard_sweep_fold": (C.c_int, [C.c_void_p]),
     "sbmbp_shard_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int]),
     "sbmbp_shard_msgdiff_partial": (C.c_int, [C.c_void_p]),
@@ -142,6 +143,7 @@ SYMBOLS = {
     "sbmbp_comm_init_rank": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_int, C.c_int]),
     "sbmbp_comm_init_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "sbmbp_comm_init_callbacks": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(CommCallbacks)]),
+    "sbmbp_comm_init_null": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "sbmbp_comm_destroy": (None, [C.c_void_p]),
     "sbmbp_comm_abort": (None, [C.c_void_p]),
     "sbmbp_comm_rank": (C.c_int, [C.c_void_p]),

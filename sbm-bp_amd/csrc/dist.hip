@@ -310,7 +310,7 @@ struct local_group {
 }  // namespace
 
 struct sbmbp_comm {
-    int kind = 0;  // 0 rccl, 1 local, 2 callbacks
+    int kind = 0;  // 0 rccl, 1 local, 2 callbacks, 3 null (measurement: one rank of a W-rank plan alone, peers never answer)
     int rank = 0, world = 1, device = -1;
     ncclComm_t halo = nullptr, red = nullptr;
     std::shared_ptr<local_group> grp;
@@ -340,7 +340,7 @@ u64 sum_counts(const u64 *c, int n) { u64 s = 0; for (int i = 0; i < n; ++i) s +
 int comm_exchange(sbmbp_comm *c, const double *send, const u64 *send_counts, double *recv, const u64 *recv_counts, int width,
                   hipStream_t stream) {
     const int W = c->world;
-    if (W == 1) return SBMBP_OK;
+    if (W == 1 || c->kind == 3) return SBMBP_OK;
     if (c->kind == 0) {
         NCCLCHK(ncclGroupStart());
         u64 so = 0, ro = 0;
@@ -398,6 +398,10 @@ int comm_exchange(sbmbp_comm *c, const double *send, const u64 *send_counts, dou
 int comm_allgather(sbmbp_comm *c, const double *in, size_t n, double *out, hipStream_t stream) {
     const int W = c->world;
     if (W == 1) { HIPCHK(hipMemcpyAsync(out, in, n * 8, hipMemcpyDeviceToDevice, stream)); return SBMBP_OK; }
+    if (c->kind == 3) {  // every peer "reports" what this rank does
+        for (int p = 0; p < W; ++p) HIPCHK(hipMemcpyAsync(out + size_t(p) * n, in, n * 8, hipMemcpyDeviceToDevice, stream));
+        return SBMBP_OK;
+    }
     if (c->kind == 0) { NCCLCHK(ncclAllGather(in, out, n, ncclDouble, c->red, stream)); return SBMBP_OK; }
     if (c->kind == 1) {
         local_group &g = *c->grp;
@@ -427,7 +431,7 @@ int comm_allgather(sbmbp_comm *c, const double *in, size_t n, double *out, hipSt
 // in-place all-reduce (op 0 sum, 1 max). Sums are taken in rank order on the non-RCCL transports.
 int comm_allreduce(sbmbp_comm *c, double *buf, size_t n, int op, hipStream_t stream) {
     const int W = c->world;
-    if (W == 1 || n == 0) return SBMBP_OK;
+    if (W == 1 || n == 0 || c->kind == 3) return SBMBP_OK;
     if (c->kind == 0) { NCCLCHK(ncclAllReduce(buf, buf, n, ncclDouble, op == 0 ? ncclSum : ncclMax, c->red, stream)); return SBMBP_OK; }
     if (c->kind == 1) {
         local_group &g = *c->grp;
@@ -525,6 +529,16 @@ int sbmbp_comm_init_callbacks(sbmbp_comm_t **out, int n_ranks, int rank, const s
     return SBMBP_OK;
 }
 
+int sbmbp_comm_init_null(sbmbp_comm_t **out, int n_ranks, int rank) {
+    if (!out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return SBMBP_ERR_ARG;
+    auto *c = new sbmbp_comm();
+    c->kind = 3;
+    c->rank = rank;
+    c->world = n_ranks;
+    *out = c;
+    return SBMBP_OK;
+}
+
 void sbmbp_comm_destroy(sbmbp_comm_t *c) {
     if (!c) return;
     if (c->halo) ncclCommDestroy(c->halo);
@@ -552,7 +566,7 @@ void sbmbp_comm_abort(sbmbp_comm_t *c) {
 
 int sbmbp_comm_rank(const sbmbp_comm_t *c) { return c ? c->rank : -1; }
 int sbmbp_comm_size(const sbmbp_comm_t *c) { return c ? c->world : 0; }
-const char *sbmbp_comm_transport(const sbmbp_comm_t *c) { return !c ? "" : (c->kind == 0 ? "rccl" : (c->kind == 1 ? "local" : "callbacks")); }
+const char *sbmbp_comm_transport(const sbmbp_comm_t *c) { return !c ? "" : (c->kind == 0 ? "rccl" : (c->kind == 1 ? "local" : (c->kind == 2 ? "callbacks" : "null"))); }
 
 }  // extern "C"
 
@@ -567,6 +581,9 @@ struct sbmbp_dist {
     shard_plan plan;
     sbmbp_engine_t *eng = nullptr;
     hipStream_t s_compute = nullptr, s_comm = nullptr;
+    hipStream_t s_aux[2] = {nullptr, nullptr};  // the row chunks of a sweep alternate between two streams: a chunk's tail overlaps the next chunk
+    hipEvent_t ev_start = nullptr;
+    bool two_streams = true;
     std::vector<hipEvent_t> ev_chunk, ev_xchg;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     double *d_psi[2] = {nullptr, nullptr};
@@ -604,8 +621,9 @@ inline const u64 *cp_row(const std::vector<u64> &v, u32 c, int W) { return v.dat
 
 // ship rows over the exchange stream: the send rows are final at `ready` (recorded on the compute stream by the caller),
 // `done` is recorded on the exchange stream behind the transfer
-int ship(sbmbp_dist *d, const double *send, const u64 *sc, double *recv, const u64 *rc, int width, hipEvent_t ready, hipEvent_t done) {
-    HIPCHK(hipEventRecord(ready, d->s_compute));
+int ship(sbmbp_dist *d, const double *send, const u64 *sc, double *recv, const u64 *rc, int width, hipEvent_t ready, hipEvent_t done,
+         hipStream_t producer = nullptr) {
+    HIPCHK(hipEventRecord(ready, producer ? producer : d->s_compute));
     HIPCHK(hipStreamWaitEvent(d->s_comm, ready, 0));
     CHK(comm_exchange(d->comm, send, sc, recv, rc, width, d->s_comm));
     HIPCHK(hipEventRecord(done, d->s_comm));
@@ -641,8 +659,10 @@ int refresh_message_halo(sbmbp_dist *d, u32 j) {
     return SBMBP_OK;
 }
 
-int gather_red(sbmbp_dist *d) {  // every rank's red[0..Q] -> red[32 + r (Q+1) ..] on all ranks: ONE collective per sweep
-    return comm_allgather(d->comm, d->d_red, d->Q + 1, d->d_red + SBMBP_RED_GATHER_OFFSET, d->s_compute);
+// every rank's first `rows` rows of (Q+1) reduction values -> behind red + SBMBP_RED_GATHER_OFFSET on all ranks, in rank
+// order: ONE collective per sweep; k_finalize folds the gathered rows identically everywhere
+int gather_red(sbmbp_dist *d, u32 rows) {
+    return comm_allgather(d->comm, d->d_red, size_t(rows) * (d->Q + 1), d->d_red + SBMBP_RED_GATHER_OFFSET, d->s_compute);
 }
 
 int reduce_red(sbmbp_dist *d, size_t n_sum, size_t n_max) {
@@ -677,18 +697,26 @@ int queue_sweep_psi(sbmbp_dist *d, u32 j) {
     const int rb_next = sbmbp_shard_read_buffer(d->eng, j + 1);
     hipEvent_t *ev = phase_quad(d);
     if (ev) HIPCHK(hipEventRecord(ev[0], d->s_compute));
+    const bool split = d->two_streams && P.n_chunks > 1;
+    if (split) HIPCHK(hipEventRecord(d->ev_start, d->s_compute));  // finalize of the last sweep and its exchanges are behind this point
     for (u32 c = 0; c < P.n_chunks; ++c) {
-        CHK(sbmbp_shard_sweep_chunk(d->eng, j, c));
+        hipStream_t sc = split ? d->s_aux[c & 1] : d->s_compute;
+        if (split) HIPCHK(hipStreamWaitEvent(sc, d->ev_start, 0));
+        CHK(sbmbp_shard_sweep_chunk_on(d->eng, j, c, sc));
         if (d->world > 1) {
             const u64 off = P.send_off_c[c];
             CHK(ship(d, d->d_sendbuf + off * d->ncomp, cp_row(P.send_counts_cp, c, d->world), d->d_recvbuf[rb_next] + P.stage_off_c[c] * d->ncomp,
-                     cp_row(P.recv_counts_cp, c, d->world), int(d->ncomp), d->ev_chunk[c], d->ev_xchg[c]));
+                     cp_row(P.recv_counts_cp, c, d->world), int(d->ncomp), d->ev_chunk[c], d->ev_xchg[c], sc));
+        } else if (split) {
+            HIPCHK(hipEventRecord(d->ev_chunk[c], sc));
         }
     }
+    if (split)  // the folds read every chunk's partials
+        for (u32 c = 0; c < P.n_chunks; ++c) HIPCHK(hipStreamWaitEvent(d->s_compute, d->ev_chunk[c], 0));
     if (ev) HIPCHK(hipEventRecord(ev[1], d->s_compute));
-    CHK(sbmbp_shard_sweep_fold(d->eng));  // local folds overlap with the last chunk's exchange (they do not touch the halo)
-    CHK(gather_red(d));
-    CHK(sbmbp_shard_finalize(d->eng, 0, u32(d->world), 0));
+    CHK(sbmbp_shard_sweep_fold(d->eng));  // the local fold overlaps with the last chunk's exchange (it does not touch the halo)
+    CHK(gather_red(d, SBMBP_FOLD_ROWS));
+    CHK(sbmbp_shard_finalize(d->eng, 0, u32(d->world) * SBMBP_FOLD_ROWS, 0));
     if (ev) HIPCHK(hipEventRecord(ev[2], d->s_compute));
     if (d->world > 1)  // the next sweep reads the receive buffers: its kernels wait for the exchanges here
         for (u32 c = 0; c < P.n_chunks; ++c) HIPCHK(hipStreamWaitEvent(d->s_compute, d->ev_xchg[c], 0));
@@ -713,8 +741,8 @@ int queue_sweep_explicit(sbmbp_dist *d, u32 j, double damping, bool ship_margina
         }
     }
     CHK(sbmbp_shard_sweep_fold(d->eng));
-    CHK(gather_red(d));
-    CHK(sbmbp_shard_finalize(d->eng, 0, u32(d->world), 1));
+    CHK(gather_red(d, SBMBP_FOLD_ROWS));
+    CHK(sbmbp_shard_finalize(d->eng, 0, u32(d->world) * SBMBP_FOLD_ROWS, 1));
     if (ship_marginals && d->world > 1)
         for (u32 c = 0; c < P.n_chunks; ++c) HIPCHK(hipStreamWaitEvent(d->s_compute, d->ev_xchg[c], 0));
     return SBMBP_OK;
@@ -740,7 +768,7 @@ int begin_run(sbmbp_dist *d, double crit, bool hinted, bool marginal_halo) {
     if (marginal_halo) CHK(refresh_marginal_halo(d, 0));
     CHK(sbmbp_shard_begin(d->eng, crit, hinted ? 1 : 0));
     CHK(sbmbp_shard_field_partial(d->eng, 0));
-    CHK(gather_red(d));
+    CHK(gather_red(d, 1));
     CHK(sbmbp_shard_finalize(d->eng, 1, u32(d->world), 0));
     return SBMBP_OK;
 }
@@ -789,6 +817,7 @@ int run(sbmbp_dist *d, double crit, u32 max_sweeps, double damping, int *niter, 
         }
     }
     HIPCHK(hipStreamSynchronize(d->s_comm));
+    for (auto sx : d->s_aux) HIPCHK(hipStreamSynchronize(sx));
     HIPCHK(hipStreamSynchronize(d->s_compute));
     sbmbp_conv_state poll;
     CHK(sbmbp_shard_poll(d->eng, &poll));  // also collects the kernel timing events of the engine
@@ -815,7 +844,7 @@ int refresh_for_reductions(sbmbp_dist *d) {
     CHK(sbmbp_shard_set_incoming(d->eng, 1));
     CHK(sbmbp_shard_begin(d->eng, -1.0, 0));  // parameter block in sync with the host mirror
     CHK(sbmbp_shard_field_partial(d->eng, 0));
-    CHK(gather_red(d));
+    CHK(gather_red(d, 1));
     CHK(sbmbp_shard_finalize(d->eng, 1, u32(d->world), 0));
     return SBMBP_OK;
 }
@@ -941,8 +970,9 @@ int sbmbp_dist_create(sbmbp_dist_t **out, sbmbp_comm_t *comm, const sbmbp_graph_
         CHK(dalloc(&d->d_recvbuf[t], size_t(P.n_halo) * d->ncomp));
         HIPCHK(hipMemset(d->d_recvbuf[t], 0, std::max<size_t>(1, size_t(P.n_halo) * d->ncomp) * 8));
     }
-    CHK(dalloc(&d->d_red, 8192));
-    HIPCHK(hipMemset(d->d_red, 0, 8192 * 8));
+    const size_t red_cap = std::max<size_t>(8192, SBMBP_RED_GATHER_OFFSET + size_t(d->world) * SBMBP_FOLD_ROWS * (SBMBP_MAX_Q + 1));
+    CHK(dalloc(&d->d_red, red_cap));
+    HIPCHK(hipMemset(d->d_red, 0, red_cap * 8));
     CHK(dalloc(&d->d_sendbuf, P.send_idx_chunked.size() * d->ncomp));
     CHK(dalloc(&d->d_send_idx, P.send_idx_chunked.size()));
     CHK(dalloc(&d->d_stage_to_halo, P.n_halo));
@@ -977,6 +1007,9 @@ int sbmbp_dist_create(sbmbp_dist_t **out, sbmbp_comm_t *comm, const sbmbp_graph_
     CHK(sbmbp_shard_create(&d->eng, &desc, Q, dc, d->device));
     HIPCHK(hipStreamCreateWithFlags(&d->s_compute, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&d->s_comm, hipStreamNonBlocking));
+    for (auto &sx : d->s_aux) HIPCHK(hipStreamCreateWithFlags(&sx, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&d->ev_start, hipEventDisableTiming));
+    if (const char *ts = std::getenv("SBMBP_SHARD_STREAMS")) d->two_streams = std::atoi(ts) > 1;  // A/B: 1 = all chunks on the compute stream
     CHK(sbmbp_set_stream(d->eng, d->s_compute));
     CHK(sbmbp_shard_set_io(d->eng, P.snd_ptr.data(), P.snd_slot.data(), d->d_sendbuf, d->d_recvbuf[0], d->d_recvbuf[1], d->ncomp));
     d->ev_chunk.resize(P.n_chunks);
@@ -1007,6 +1040,7 @@ void sbmbp_dist_destroy(sbmbp_dist_t *d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
     if (d->s_comm) (void)hipStreamSynchronize(d->s_comm);
+    for (auto sx : d->s_aux) if (sx) (void)hipStreamSynchronize(sx);
     if (d->s_compute) (void)hipStreamSynchronize(d->s_compute);
     if (d->eng) { (void)sbmbp_set_stream(d->eng, nullptr); sbmbp_destroy(d->eng); }
     void *ptrs[] = {d->d_psi[0], d->d_psi[1], d->d_red, d->d_sendbuf, d->d_recvbuf[0], d->d_recvbuf[1], d->d_msg_send, d->d_psi_all,
@@ -1017,6 +1051,8 @@ void sbmbp_dist_destroy(sbmbp_dist_t *d) {
     for (auto ev : d->phase_ev) if (ev) (void)hipEventDestroy(ev);
     if (d->ev_a) (void)hipEventDestroy(d->ev_a);
     if (d->ev_b) (void)hipEventDestroy(d->ev_b);
+    if (d->ev_start) (void)hipEventDestroy(d->ev_start);
+    for (auto sx : d->s_aux) if (sx) (void)hipStreamDestroy(sx);
     if (d->s_comm) (void)hipStreamDestroy(d->s_comm);
     if (d->s_compute) (void)hipStreamDestroy(d->s_compute);
     delete d;

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -1639,8 +1640,11 @@ int sbmbp_shard_field_partial(sbmbp_engine_t *e, uint32_t j) {
     return SBMBP_OK;
 }
 
-int sbmbp_shard_sweep_chunk(sbmbp_engine_t *e, uint32_t j, uint32_t c) {
+int sbmbp_shard_sweep_chunk(sbmbp_engine_t *e, uint32_t j, uint32_t c) { return sbmbp_shard_sweep_chunk_on(e, j, c, e ? e->stream : nullptr); }
+
+int sbmbp_shard_sweep_chunk_on(sbmbp_engine_t *e, uint32_t j, uint32_t c, void *hip_stream) {
     IS_SHARD(e);
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     if (c + 1 >= e->chunk_blk.size()) { set_error("chunk index out of range"); return SBMBP_ERR_ARG; }
     const int mc = (e->cur + int(j)) & 1, pc = (e->pcur + int(j)) & 1;
     double *Mio = e->d_M[mc ^ 1];
@@ -1670,34 +1674,39 @@ int sbmbp_shard_sweep_chunk(sbmbp_engine_t *e, uint32_t j, uint32_t c) {
         }
         e0 = e->ev[e->ev_used++];
         e1 = e->ev[e->ev_used++];
-        HIPCHK(hipEventRecord(e0, e->stream));
+        HIPCHK(hipEventRecord(e0, stream));
     }
+    // XCD-aware numbering of the chunk launches too (1 chunk 0.371 -> 0.363 ms, 4 chunks 0.419 -> 0.412 ms per rank of the 8-rank C3 plan)
+    static const int shard_xcd = std::getenv("SBMBP_SHARD_XCD") ? std::atoi(std::getenv("SBMBP_SHARD_XCD")) : SBMBP_XCD_REMAP;
     if (nb)
     {
         if (io.snd_ptr) {
-            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, true>), dim3(nb), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr, Mio,
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, true>), dim3(shard_xcd ? xcd_grid(nb) : nb), dim3(FTPB), 0, stream, e->d_row_ptr, e->d_nbr, Mio,
                                                 psi_old, psi_new, e->d_blk_row + b0, e->d_blk_e0 + b0, e->d_P, int(e->dc),
-                                                e->d_partials + size_t(b0) * (e->Q + 1), (const int32_t *)nullptr, io, nb, 0, Mcmp, first));
+                                                e->d_partials + size_t(b0) * (e->Q + 1), (const int32_t *)nullptr, io, nb, shard_xcd, Mcmp, first));
         } else {
-            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, false>), dim3(nb), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr, Mio,
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, false>), dim3(nb), dim3(FTPB), 0, stream, e->d_row_ptr, e->d_nbr, Mio,
                                                 psi_old, psi_new, e->d_blk_row + b0, e->d_blk_e0 + b0, e->d_P, int(e->dc),
                                                 e->d_partials + size_t(b0) * (e->Q + 1), (const int32_t *)nullptr, io, nb, 0, Mcmp, first));
         }
     }
-    if (e->timing && nb) HIPCHK(hipEventRecord(e1, e->stream));
+    if (e->timing && nb) HIPCHK(hipEventRecord(e1, stream));
     if (nh)
-        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi_hub<QQ>), dim3(nh), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi_hub<QQ>), dim3(nh), dim3(BLOCK), 0, stream, e->d_row_ptr,
                                             e->d_nbr, Mio, psi_old, psi_new, e->d_hub_row + h0, e->d_hub_blk + h0, e->d_P,
                                             int(e->dc), e->d_partials, (const int32_t *)nullptr, io, Mcmp, first));
     HIPCHK(hipGetLastError());
     return SBMBP_OK;
 }
 
+// ONE launch: the block partials of all chunks -> SBMBP_FOLD_ROWS rows in red (workgroups without rows write zeros, neutral
+// for the sums and for the maximum of non-negative differences). The caller all-gathers these rows of every rank and
+// k_finalize folds the lot: no second fold stage per rank.
 int sbmbp_shard_sweep_fold(sbmbp_engine_t *e) {
     IS_SHARD(e);
-    uint32_t rows = e->n_blk;
-    const double *part = fold_stage(e, &rows, int(e->Q), 1, e->Q + 1);
-    hipLaunchKernelGGL(k_fold_stage, dim3(1), dim3(BLOCK), 0, e->stream, part, rows, rows, int(e->Q), 1, e->Q + 1, e->d_red);
+    const uint32_t rows = e->n_blk;
+    const uint32_t chunk = std::max<uint32_t>(1, (rows + SBMBP_FOLD_ROWS - 1) / SBMBP_FOLD_ROWS);
+    hipLaunchKernelGGL(k_fold_stage, dim3(SBMBP_FOLD_ROWS), dim3(BLOCK), 0, e->stream, e->d_partials, rows, chunk, int(e->Q), 1, e->Q + 1, e->d_red);
     HIPCHK(hipGetLastError());
     return SBMBP_OK;
 }
@@ -1710,7 +1719,7 @@ int sbmbp_shard_sweep_partial(sbmbp_engine_t *e, uint32_t j) {
 
 int sbmbp_shard_finalize(sbmbp_engine_t *e, int mode, uint32_t n_rows, int md_exact) {
     IS_SHARD(e);
-    if ((mode != 0 && mode != 1) || n_rows == 0 || SBMBP_RED_GATHER_OFFSET + uint64_t(n_rows) * (e->Q + 1) > 8192) return SBMBP_ERR_ARG;
+    if ((mode != 0 && mode != 1) || n_rows == 0 || n_rows > 64u * SBMBP_FOLD_ROWS) return SBMBP_ERR_ARG;
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, e->stream, e->d_red + SBMBP_RED_GATHER_OFFSET, n_rows, int(e->Q), mode, e->d_P, e->d_hist, e->hist_cap, md_exact);
     HIPCHK(hipGetLastError());
     return SBMBP_OK;
