@@ -107,6 +107,17 @@ struct sbmbp_engine {
     size_t ev_used = 0;
 };
 
+// The current device is a per-thread setting of the HIP runtime: every entry point that takes an engine selects the
+// engine's GPU for the duration of the call and puts the caller's choice back (a process may hold engines on several GPUs).
+struct device_scope {
+    int prev = -1;
+    explicit device_scope(const sbmbp_engine *e) {
+        if (e && hipGetDevice(&prev) == hipSuccess && prev != e->device) (void)hipSetDevice(e->device);
+        else prev = -1;
+    }
+    ~device_scope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 namespace {
 
 template <typename T> int dev_alloc(sbmbp_engine *e, T **p, size_t count) {
@@ -937,6 +948,7 @@ void sbmbp_destroy(sbmbp_engine_t *e) {
 }
 
 int sbmbp_set_stream(sbmbp_engine_t *e, void *hip_stream) {
+    device_scope dev_(e);
     if (!e) return SBMBP_ERR_ARG;
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->own_stream && e->stream) HIPCHK(hipStreamDestroy(e->stream));
@@ -968,6 +980,7 @@ static int upload_labels(sbmbp_engine_t *e, const int32_t *conf, const uint32_t 
 
 int sbmbp_init_messages(sbmbp_engine_t *e, uint32_t flag, const int32_t *conf, const uint32_t *true_conf, uint32_t seed,
                         int conditional) {
+    device_scope dev_(e);
     if (!e) return SBMBP_ERR_ARG;
     if (flag >= 4) { set_error("bp_messages_init_flag must be < 4"); return SBMBP_ERR_ARG; }  // assert at bp.cpp:106
     if (flag != 0 && !conf) { set_error("init flag != 0 needs a conf vector"); return SBMBP_ERR_ARG; }
@@ -1038,6 +1051,7 @@ int sbmbp_host_init_state(const sbmbp_graph_t *g, uint32_t Q, uint32_t flag, con
 }
 
 int sbmbp_init_messages_device(sbmbp_engine_t *e, uint64_t seed, const uint32_t *true_conf) {
+    device_scope dev_(e);
     if (!e) return SBMBP_ERR_ARG;
     CHK(upload_labels(e, nullptr, true_conf, 0, 0));
     // random marginals (counter-based generator keyed by the GLOBAL row id, so shards draw what the single engine draws);
@@ -1058,11 +1072,13 @@ int sbmbp_init_messages_device(sbmbp_engine_t *e, uint64_t seed, const uint32_t 
 }
 
 int sbmbp_set_params(sbmbp_engine_t *e, const double *cab, const uint32_t *na, double beta) {
+    device_scope dev_(e);
     if (!e || !cab || !na) return SBMBP_ERR_ARG;
     apply_params_host(e, cab, na, beta);
     return upload_params(e, 0.0);
 }
 int sbmbp_get_params(sbmbp_engine_t *e, double *cab, uint32_t *na) {
+    device_scope dev_(e);
     if (!e || !e->have_params) return SBMBP_ERR_STATE;
     if (cab) std::copy(e->cab.begin(), e->cab.end(), cab);
     if (na) std::copy(e->na.begin(), e->na.end(), na);
@@ -1111,6 +1127,7 @@ static int download_messages(sbmbp_engine *e, const double *src, double *msg_out
 }
 
 int sbmbp_set_state(sbmbp_engine_t *e, const double *psi, const double *msg_out) {
+    device_scope dev_(e);
     if (!e) return SBMBP_ERR_ARG;
     if (psi) HIPCHK(hipMemcpyAsync(e->d_psi[e->pcur], psi, size_t(e->N) * e->Q * 8, hipMemcpyHostToDevice, e->stream));
     if (msg_out && e->E2) CHK(upload_messages(e, msg_out, e->d_M[e->cur]));
@@ -1126,6 +1143,7 @@ int sbmbp_set_state(sbmbp_engine_t *e, const double *psi, const double *msg_out)
     return SBMBP_OK;
 }
 int sbmbp_get_state(sbmbp_engine_t *e, double *psi, double *msg_out) {
+    device_scope dev_(e);
     if (!e) return SBMBP_ERR_ARG;
     if (psi) HIPCHK(hipMemcpyAsync(psi, e->d_psi[e->pcur], size_t(e->N) * e->Q * 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -1133,6 +1151,7 @@ int sbmbp_get_state(sbmbp_engine_t *e, double *psi, double *msg_out) {
     return SBMBP_OK;
 }
 int sbmbp_get_field(sbmbp_engine_t *e, double *h) {
+    device_scope dev_(e);
     if (!e || !h) return SBMBP_ERR_ARG;
     NOT_SHARD(e);
     CHK(refresh_field(e));
@@ -1144,6 +1163,7 @@ int sbmbp_get_field(sbmbp_engine_t *e, double *h) {
 }
 
 int sbmbp_set_schedule(sbmbp_engine_t *e, double field_mix, uint32_t check_every) {
+    device_scope dev_(e);
     if (!e || !(field_mix > 0.0) || field_mix > 1.0 || check_every < 1) return SBMBP_ERR_ARG;
     e->field_mix = field_mix;
     e->check_every = check_every;
@@ -1151,6 +1171,7 @@ int sbmbp_set_schedule(sbmbp_engine_t *e, double field_mix, uint32_t check_every
 }
 
 int sbmbp_set_learning_schedule(sbmbp_engine_t *e, double field_mix, double snap) {
+    device_scope dev_(e);
     if (!e || !(field_mix > 0.0) || field_mix > 1.0 || !(snap >= 0.0)) return SBMBP_ERR_ARG;
     e->learn_field_mix = field_mix;
     e->learn_snap = snap;
@@ -1158,17 +1179,20 @@ int sbmbp_set_learning_schedule(sbmbp_engine_t *e, double field_mix, double snap
 }
 
 int sbmbp_set_gather_mode(sbmbp_engine_t *e, int mode) {
+    device_scope dev_(e);
     if (!e || mode < 0 || mode > 1) return SBMBP_ERR_ARG;
     e->gather_mode = mode;
     return SBMBP_OK;
 }
 
 int sbmbp_converge(sbmbp_engine_t *e, double crit, uint32_t max_sweeps, double damping, int *niter, double *last) {
+    device_scope dev_(e);
     if (!e) return SBMBP_ERR_ARG;
     NOT_SHARD(e);
     return run_sweeps(e, crit, max_sweeps, damping, niter, last);
 }
 int sbmbp_sweep(sbmbp_engine_t *e, double damping, uint32_t n_sweeps, double *last) {
+    device_scope dev_(e);
     if (!e) return SBMBP_ERR_ARG;
     NOT_SHARD(e);
     const uint32_t keep = e->check_every;
@@ -1179,38 +1203,45 @@ int sbmbp_sweep(sbmbp_engine_t *e, double damping, uint32_t n_sweeps, double *la
 }
 
 int sbmbp_free_energy(sbmbp_engine_t *e, double *f, double *parts) {
+    device_scope dev_(e);
     if (!e) return SBMBP_ERR_ARG;
     NOT_SHARD(e);
     return free_energy_impl(e, f, parts);
 }
 int sbmbp_entropy(sbmbp_engine_t *e, double *ent, double *parts) {
+    device_scope dev_(e);
     if (!e) return SBMBP_ERR_ARG;
     NOT_SHARD(e);
     return entropy_impl(e, ent, parts);
 }
 int sbmbp_set_nonedge_mode(sbmbp_engine_t *e, int mode, int order) {
+    device_scope dev_(e);
     if (!e || mode < 0 || mode > 2 || order < 0 || order > 4) return SBMBP_ERR_ARG;
     e->nonedge_mode = mode;
     e->series_order = order;
     return SBMBP_OK;
 }
 int sbmbp_em_expectations(sbmbp_engine_t *e, double *na_e, double *nna_e, double *cab_e) {
+    device_scope dev_(e);
     if (!e) return SBMBP_ERR_ARG;
     NOT_SHARD(e);
     return em_expect(e, na_e, nna_e, cab_e);
 }
 int sbmbp_confusion(sbmbp_engine_t *e, double *C) {
+    device_scope dev_(e);
     if (!e || !C) return SBMBP_ERR_ARG;
     NOT_SHARD(e);
     return overlap_impl(e, nullptr, C);
 }
 int sbmbp_overlap(sbmbp_engine_t *e, double *ov) {
+    device_scope dev_(e);
     if (!e || !ov) return SBMBP_ERR_ARG;
     NOT_SHARD(e);
     return overlap_impl(e, ov, nullptr);
 }
 
 int sbmbp_inference(sbmbp_engine_t *e, float conv_crit, uint32_t time_conv, float dumping_rate, sbmbp_infer_result *out) {
+    device_scope dev_(e);
     if (!e || !out) return SBMBP_ERR_ARG;
     NOT_SHARD(e);
     // belief_propagation::inference (bp.cpp:77-99); crit and damping arrive as float, compared as double (:406)
@@ -1233,6 +1264,7 @@ int sbmbp_inference(sbmbp_engine_t *e, float conv_crit, uint32_t time_conv, floa
 
 int sbmbp_learning(sbmbp_engine_t *e, float learning_conv_crit, uint32_t learning_max_time, float learning_rate,
                    float dumping_rate, sbmbp_learn_result *out) {
+    device_scope dev_(e);
     if (!e || !out) return SBMBP_ERR_ARG;
     NOT_SHARD(e);
     if (!e->have_params || !e->have_state) { set_error("set_params and init_messages must precede learning"); return SBMBP_ERR_STATE; }
@@ -1289,6 +1321,7 @@ int sbmbp_learning(sbmbp_engine_t *e, float learning_conv_crit, uint32_t learnin
 }
 
 int sbmbp_get_stats(sbmbp_engine_t *e, sbmbp_stats *out) {
+    device_scope dev_(e);
     if (!e || !out) return SBMBP_ERR_ARG;
     out->sweeps = e->sweeps;
     out->edge_msg_updates = e->sweeps * e->E2;
@@ -1303,6 +1336,7 @@ int sbmbp_get_stats(sbmbp_engine_t *e, sbmbp_stats *out) {
     return SBMBP_OK;
 }
 int sbmbp_reset_stats(sbmbp_engine_t *e) {
+    device_scope dev_(e);
     if (!e) return SBMBP_ERR_ARG;
     e->sweeps = 0;
     e->psi_sweeps = 0;
@@ -1311,6 +1345,7 @@ int sbmbp_reset_stats(sbmbp_engine_t *e) {
     return SBMBP_OK;
 }
 int sbmbp_set_timing(sbmbp_engine_t *e, int on) {
+    device_scope dev_(e);
     if (!e) return SBMBP_ERR_ARG;
     e->timing = on != 0;
     return SBMBP_OK;
@@ -1459,6 +1494,7 @@ int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *d, uint32_t
 
 int sbmbp_shard_set_labels(sbmbp_engine_t *e, const int32_t *conf, const uint32_t *true_conf, uint32_t flag, int conditional,
                            int any_clamp_global) {
+    device_scope dev_(e);
     IS_SHARD(e);
     CHK(upload_labels(e, conf, true_conf, flag, conditional));
     // whether clamped rows exist is a property of the whole graph: every shard takes the same kernel variants
@@ -1468,6 +1504,7 @@ int sbmbp_shard_set_labels(sbmbp_engine_t *e, const int32_t *conf, const uint32_
 }
 
 int sbmbp_shard_query(sbmbp_engine_t *e, int what) {
+    device_scope dev_(e);
     if (!e) return SBMBP_ERR_ARG;
     switch (what) {
         case 0: return e->w_positive ? 1 : 0;
@@ -1480,6 +1517,7 @@ int sbmbp_shard_query(sbmbp_engine_t *e, int what) {
 }
 
 int sbmbp_shard_set_incoming(sbmbp_engine_t *e, int source) {
+    device_scope dev_(e);
     IS_SHARD(e);
     if (source != 0 && !(source == 1 && e->d_rev)) return SBMBP_ERR_ARG;
     e->incoming_src = source;
@@ -1492,6 +1530,7 @@ void *sbmbp_shard_msg_halo(sbmbp_engine_t *e, uint32_t j) {
 }
 
 int sbmbp_shard_pack_msgs(sbmbp_engine_t *e, uint32_t j, const uint32_t *d_edge_idx, uint32_t n, double *d_out) {
+    device_scope dev_(e);
     IS_SHARD(e);
     if (n == 0) return SBMBP_OK;
     const int mc = int(e->Q) - 1;  // records are rows of Q-1 words: the generic row gather copies them verbatim
@@ -1505,6 +1544,7 @@ int sbmbp_shard_pack_msgs(sbmbp_engine_t *e, uint32_t j, const uint32_t *d_edge_
 // message-gather form of sweep j on a shard (any damping, clamped rows, dc 2, zeros in cab): incoming messages of the cut
 // edges are read from the records the caller received behind the own ones (sbmbp_shard_msg_halo of the same j)
 int sbmbp_shard_sweep_explicit(sbmbp_engine_t *e, uint32_t j, double damping) {
+    device_scope dev_(e);
     IS_SHARD(e);
     if (!e->d_rev) { set_error("shard was created without a reverse index"); return SBMBP_ERR_STATE; }
     const int mc = (e->cur + int(j)) & 1, pc = (e->pcur + int(j)) & 1;
@@ -1551,6 +1591,7 @@ int sbmbp_shard_sweep_explicit(sbmbp_engine_t *e, uint32_t j, double damping) {
 // the convergence state without blocking the host: record copies it into page-locked slot 0/1 behind the work queued so
 // far, wait blocks until that point of the stream and returns it
 int sbmbp_shard_state_record(sbmbp_engine_t *e, int slot) {
+    device_scope dev_(e);
     IS_SHARD(e);
     if (slot < 0 || slot > 1) return SBMBP_ERR_ARG;
     if (!e->h_cs) {
@@ -1564,6 +1605,7 @@ int sbmbp_shard_state_record(sbmbp_engine_t *e, int slot) {
     return SBMBP_OK;
 }
 int sbmbp_shard_state_wait(sbmbp_engine_t *e, int slot, sbmbp_conv_state *out) {
+    device_scope dev_(e);
     IS_SHARD(e);
     if (slot < 0 || slot > 1 || !out || !e->h_cs) return SBMBP_ERR_ARG;
     HIPCHK(hipEventSynchronize(e->ev_cs[slot]));
@@ -1577,6 +1619,7 @@ int sbmbp_shard_state_wait(sbmbp_engine_t *e, int slot, sbmbp_conv_state *out) {
 }
 
 int sbmbp_shard_begin(sbmbp_engine_t *e, double crit, int hinted) {
+    device_scope dev_(e);
     IS_SHARD(e);
     if (!e->have_params || !e->have_state) { set_error("set_params and an initial state must precede shard sweeps"); return SBMBP_ERR_STATE; }
     if (hinted && !e->w_positive) { set_error("the marginal-gather sweep needs every cab entry > 0"); return SBMBP_ERR_UNSUPPORTED; }
@@ -1587,6 +1630,7 @@ int sbmbp_shard_read_buffer(sbmbp_engine_t *e, uint32_t j) { return (e && e->sha
 
 int sbmbp_shard_set_io(sbmbp_engine_t *e, const uint32_t *snd_ptr, const uint32_t *snd_slot, double *d_sendbuf,
                        const double *d_stage0, const double *d_stage1, uint32_t ncomp) {
+    device_scope dev_(e);
     IS_SHARD(e);
     if (!snd_ptr || (ncomp != e->Q && ncomp + 1 != e->Q)) return SBMBP_ERR_ARG;
     const uint32_t n_slots = snd_ptr[e->N];
@@ -1606,6 +1650,7 @@ int sbmbp_shard_set_io(sbmbp_engine_t *e, const uint32_t *snd_ptr, const uint32_
 }
 
 int sbmbp_shard_pack(sbmbp_engine_t *e, uint32_t j, const uint32_t *d_idx, uint32_t n, double *d_out, uint32_t ncomp) {
+    device_scope dev_(e);
     IS_SHARD(e);
     if (ncomp != e->Q && ncomp + 1 != e->Q) return SBMBP_ERR_ARG;
     if (n == 0) return SBMBP_OK;
@@ -1618,6 +1663,7 @@ int sbmbp_shard_pack(sbmbp_engine_t *e, uint32_t j, const uint32_t *d_idx, uint3
 }
 
 int sbmbp_shard_unpack(sbmbp_engine_t *e, uint32_t j, const double *d_in, const uint32_t *d_halo_row, uint32_t n, uint32_t ncomp) {
+    device_scope dev_(e);
     IS_SHARD(e);
     if ((ncomp != e->Q && ncomp + 1 != e->Q) || n > e->n_halo || (n && !d_halo_row)) return SBMBP_ERR_ARG;
     if (n == 0) return SBMBP_OK;
@@ -1629,6 +1675,7 @@ int sbmbp_shard_unpack(sbmbp_engine_t *e, uint32_t j, const double *d_in, const 
 }
 
 int sbmbp_shard_field_partial(sbmbp_engine_t *e, uint32_t j) {
+    device_scope dev_(e);
     IS_SHARD(e);
     const uint32_t rows_per_blk = 4096;
     const uint32_t nb = std::max<uint32_t>(1, (e->N + rows_per_blk - 1) / rows_per_blk);
@@ -1643,6 +1690,7 @@ int sbmbp_shard_field_partial(sbmbp_engine_t *e, uint32_t j) {
 int sbmbp_shard_sweep_chunk(sbmbp_engine_t *e, uint32_t j, uint32_t c) { return sbmbp_shard_sweep_chunk_on(e, j, c, e ? e->stream : nullptr); }
 
 int sbmbp_shard_sweep_chunk_on(sbmbp_engine_t *e, uint32_t j, uint32_t c, void *hip_stream) {
+    device_scope dev_(e);
     IS_SHARD(e);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     if (c + 1 >= e->chunk_blk.size()) { set_error("chunk index out of range"); return SBMBP_ERR_ARG; }
@@ -1703,6 +1751,7 @@ int sbmbp_shard_sweep_chunk_on(sbmbp_engine_t *e, uint32_t j, uint32_t c, void *
 // for the sums and for the maximum of non-negative differences). The caller all-gathers these rows of every rank and
 // k_finalize folds the lot: no second fold stage per rank.
 int sbmbp_shard_sweep_fold(sbmbp_engine_t *e) {
+    device_scope dev_(e);
     IS_SHARD(e);
     const uint32_t rows = e->n_blk;
     const uint32_t chunk = std::max<uint32_t>(1, (rows + SBMBP_FOLD_ROWS - 1) / SBMBP_FOLD_ROWS);
@@ -1712,12 +1761,14 @@ int sbmbp_shard_sweep_fold(sbmbp_engine_t *e) {
 }
 
 int sbmbp_shard_sweep_partial(sbmbp_engine_t *e, uint32_t j) {
+    device_scope dev_(e);
     IS_SHARD(e);
     for (uint32_t c = 0; c + 1 < e->chunk_blk.size(); ++c) CHK(sbmbp_shard_sweep_chunk(e, j, c));
     return sbmbp_shard_sweep_fold(e);
 }
 
 int sbmbp_shard_finalize(sbmbp_engine_t *e, int mode, uint32_t n_rows, int md_exact) {
+    device_scope dev_(e);
     IS_SHARD(e);
     if ((mode != 0 && mode != 1) || n_rows == 0 || n_rows > 64u * SBMBP_FOLD_ROWS) return SBMBP_ERR_ARG;
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, e->stream, e->d_red + SBMBP_RED_GATHER_OFFSET, n_rows, int(e->Q), mode, e->d_P, e->d_hist, e->hist_cap, md_exact);
@@ -1726,6 +1777,7 @@ int sbmbp_shard_finalize(sbmbp_engine_t *e, int mode, uint32_t n_rows, int md_ex
 }
 
 int sbmbp_shard_msgdiff_partial(sbmbp_engine_t *e) {
+    device_scope dev_(e);
     IS_SHARD(e);
     const uint64_t n = e->E2;  // message records
     if (n == 0) { HIPCHK(hipMemsetAsync(e->d_red, 0, 8, e->stream)); return SBMBP_OK; }
@@ -1739,6 +1791,7 @@ int sbmbp_shard_msgdiff_partial(sbmbp_engine_t *e) {
 }
 
 int sbmbp_shard_rowsums_partial(sbmbp_engine_t *e) {
+    device_scope dev_(e);
     IS_SHARD(e);
     const uint32_t Q = e->Q, T = 2 * Q + Q * Q;
     const uint32_t rows_per_blk = 512;  // one thread per output entry loops over staged rows: keep chunks small, workgroups many
@@ -1751,6 +1804,7 @@ int sbmbp_shard_rowsums_partial(sbmbp_engine_t *e) {
 }
 
 int sbmbp_shard_poll(sbmbp_engine_t *e, sbmbp_conv_state *out) {
+    device_scope dev_(e);
     IS_SHARD(e);
     if (!out) return SBMBP_ERR_ARG;
     conv_state cs;
@@ -1765,6 +1819,7 @@ int sbmbp_shard_poll(sbmbp_engine_t *e, sbmbp_conv_state *out) {
 }
 
 int sbmbp_shard_commit(sbmbp_engine_t *e, uint32_t executed) {
+    device_scope dev_(e);
     IS_SHARD(e);
     e->cur = (e->cur + int(executed)) & 1;
     e->pcur = (e->pcur + int(executed)) & 1;
@@ -1813,6 +1868,7 @@ extern "C" {
 
 // red[0..4) = {sum log Z_i, sum log norm_L, e_site sum, e_edge sum} over owned rows/edges; red[4] = sum 2 d log d
 int sbmbp_shard_fe_partial(sbmbp_engine_t *e, int want_entropy) {
+    device_scope dev_(e);
     IS_SHARD(e);
     CHK(shard_materialize(e));
     double dummy[4];
@@ -1825,6 +1881,7 @@ int sbmbp_shard_fe_partial(sbmbp_engine_t *e, int want_entropy) {
 
 // out = {f_site, f_edge, e_site, e_edge} from the all-reduced red[0..5)
 int sbmbp_shard_fe_finish(sbmbp_engine_t *e, double *out) {
+    device_scope dev_(e);
     IS_SHARD(e);
     double r[5];
     HIPCHK(hipMemcpyAsync(r, e->d_red, sizeof r, hipMemcpyDeviceToHost, e->stream));
@@ -1841,6 +1898,7 @@ int sbmbp_shard_fe_finish(sbmbp_engine_t *e, double *out) {
 // moment tensors of the owned rows (orders 1..K packed) at red[0..T), adjacent-pair sums at red[T], red[T+1];
 // returns the number of doubles to all-reduce (T + 2) in *n_values and the order used in *order
 int sbmbp_shard_nonedge_partial(sbmbp_engine_t *e, int want_entropy, uint32_t *n_values, int *order) {
+    device_scope dev_(e);
     IS_SHARD(e);
     if (!n_values || !order) return SBMBP_ERR_ARG;
     const uint32_t Q = e->Q;
@@ -1877,6 +1935,7 @@ int sbmbp_shard_nonedge_partial(sbmbp_engine_t *e, int want_entropy, uint32_t *n
 // {all-pairs f, all-pairs e, adjacent f, adjacent e} over (own i, every l); after a SUM all-reduce of the 4 values
 // f_nonedge = (red[0] - red[2]) / 2N, e_nonedge = (red[1] - red[3]) / 2N   (bp.cpp:675-741).
 int sbmbp_shard_nonedge_exact_partial(sbmbp_engine_t *e, const double *d_psi_all, int want_entropy) {
+    device_scope dev_(e);
     IS_SHARD(e);
     if (!d_psi_all) return SBMBP_ERR_ARG;
     const uint32_t Q = e->Q;
@@ -1905,6 +1964,7 @@ int sbmbp_shard_nonedge_exact_partial(sbmbp_engine_t *e, const double *d_psi_all
 
 // out = {f_nonedge, e_nonedge} from the all-reduced moments and adjacent sums
 int sbmbp_shard_nonedge_finish(sbmbp_engine_t *e, int want_entropy, int order, double *out) {
+    device_scope dev_(e);
     IS_SHARD(e);
     out[0] = out[1] = 0.0;
     if (e->dc != 0 || order <= 0) return SBMBP_OK;
@@ -1942,6 +2002,7 @@ int sbmbp_shard_nonedge_finish(sbmbp_engine_t *e, int want_entropy, int order, d
 
 // red[0..2Q+Q*Q) row sums (na, nna, confusion), then the Q(Q+1)/2 EM numerators; *n_values doubles to all-reduce
 int sbmbp_shard_em_partial(sbmbp_engine_t *e, uint32_t *n_values) {
+    device_scope dev_(e);
     IS_SHARD(e);
     if (!n_values) return SBMBP_ERR_ARG;
     const uint32_t Q = e->Q, R = 2 * Q + Q * Q, T = Q * (Q + 1) / 2;
@@ -1964,6 +2025,7 @@ int sbmbp_shard_em_partial(sbmbp_engine_t *e, uint32_t *n_values) {
 }
 
 int sbmbp_shard_em_finish(sbmbp_engine_t *e, double *na_e, double *nna_e, double *cab_e) {
+    device_scope dev_(e);
     IS_SHARD(e);
     const uint32_t Q = e->Q, R = 2 * Q + Q * Q, T = Q * (Q + 1) / 2;
     std::vector<double> r(R + T);

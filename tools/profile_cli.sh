@@ -2,7 +2,7 @@
 # rocprofv3 kernel summary of one `bin/bp -m infer` run on a synthetic C3-size edge list (N=1e7, Q=4, c=10).
 # usage (repo root, GPU box): tools/profile_cli.sh r01
 set -u
-R=${1:-r01}
+R=${1:-r02}
 OUT=gpurun_out/profile_cli_$R
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -2,6 +2,8 @@
 import csv, glob, json, os, shutil, sys
 R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import source_sha
 OUT = os.path.join(ROOT, "gpurun_out", "profile_" + R)
 PROF = os.path.join(ROOT, "profiles")
 os.makedirs(PROF, exist_ok=True)
@@ -31,8 +33,17 @@ for d in sorted(glob.glob(os.path.join(OUT, "pmc_*"))):
 if counters:
     bench = json.loads(open(os.path.join(PROF, "%s_c3_bench.json" % R)).read())
     out = {"kernel": bench["roofline"]["kernel"], "workload": "C3 N=1e7 Q=4 c=10 (E2=%d)" % bench["config"]["E2"],
+           "source_sha": source_sha(),
            "command": "rocprofv3 --kernel-trace --pmc <counter> --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline (one pass per counter; tools/profile_round.sh)",
            "counters": {k: {"per_launch_mean": sum(v) / len(v), "launches": len(v)} for k, v in counters.items()}}
     json.dump(out, open(os.path.join(PROF, "%s_c3_pmc_k_sweep_psi.json" % R), "w"), indent=1)
     print(json.dumps(out["counters"]))
+for f in glob.glob(os.path.join(OUT, "budget_c3_w8_c*.json")):
+    shutil.copy(f, os.path.join(PROF, "%s_%s" % (R, os.path.basename(f))))
+for name, dst in (("bench_rehearsal3.json", "%s_small_bench_3ranks_rehearsal.json"), ("bench_C3_rccl1.json", "%s_c3_bench_rccl_1rank.json")):
+    b = os.path.join(OUT, name)
+    if os.path.exists(b):
+        line = [l for l in open(b) if l.startswith("{")]
+        if line:
+            open(os.path.join(PROF, dst % R), "w").write(line[-1])
 print("profiles/:", sorted(os.listdir(PROF)))
