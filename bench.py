@@ -208,7 +208,8 @@ def main():
         local_rank = 0
     sharded = world > 1 or args.force_sharded
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29577")
+    if "MASTER_PORT" not in os.environ:  # only a single-rank run gets here without one (launchers set it)
+        os.environ["MASTER_PORT"] = str(free_port())
     if not args.dry_run:
         torch.cuda.set_device(local_rank)
     if sharded:

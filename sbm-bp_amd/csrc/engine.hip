@@ -468,14 +468,14 @@ int site_edge_terms(sbmbp_engine *e, bool want_entropy, double out[4], double *d
     const double *Min = (e->sharded && e->incoming_src == 0) ? e->d_Min : nullptr;
     if (e->dc == 2) {
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_frame<QQ, true>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
-                                            e->d_rev, e->d_nbr, e->d_deg, M, Min, e->d_blk_row, e->d_P, 1, int(want_entropy), e->d_partials));
+                                            e->d_rev, e->d_nbr, e->d_deg, M, Min, e->d_blk_row, e->d_blk_e0, e->d_P, 1, int(want_entropy), e->d_partials));
         if (e->n_hub)
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
                                                 e->d_rev, e->d_nbr, e->d_deg, M, Min, e->d_hub_row, e->d_hub_blk, e->d_P, 1,
                                                 int(want_entropy), e->d_partials));
     } else {
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_frame<QQ, false>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
-                                            e->d_rev, e->d_nbr, e->d_deg, M, Min, e->d_blk_row, e->d_P, int(e->dc), int(want_entropy),
+                                            e->d_rev, e->d_nbr, e->d_deg, M, Min, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), int(want_entropy),
                                             e->d_partials));
         if (e->n_hub)
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_hub<QQ, false>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr,

@@ -477,6 +477,27 @@ template <int Q> __device__ __forceinline__ void row_product_wave(const double *
     }
 }
 
+#ifndef SBMBP_BATCH_RECIP
+#define SBMBP_BATCH_RECIP 1  // 1: the Q reciprocals of a lane from ONE division (prefix products), marginal-gather sweep only
+#endif
+// r[k] = 1 / x[k] for all k from one division: prefix products p_k = x_0 .. x_k, inv = 1 / p_{Q-1}, then backwards
+// r[k] = inv * p_{k-1}, inv *= x[k]. Falls back to Q divisions when the product leaves the normal range.
+template <int Q> __device__ __forceinline__ void recip_all(const double (&x)[Q], double (&r)[Q]) {
+    double p[Q];
+    p[0] = x[0];
+#pragma unroll
+    for (int k = 1; k < Q; ++k) p[k] = p[k - 1] * x[k];
+    double inv = 1.0 / p[Q - 1];
+    if (!(p[Q - 1] > 1e-280) || !(p[Q - 1] < 1e280)) {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) r[k] = 1.0 / x[k];
+        return;
+    }
+#pragma unroll
+    for (int k = Q - 1; k > 0; --k) { r[k] = inv * p[k - 1]; inv *= x[k]; }
+    r[0] = inv;
+}
+
 // b[q] = sum_t W_il[t][q] m[t]   (belief_propagation.cpp:1000-1012)
 template <int Q, bool DC2>
 __device__ __forceinline__ void edge_field(const dev_params *__restrict__ P, const double (&m)[Q], double didl, double (&b)[Q]) {
@@ -850,8 +871,15 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
             } else {
                 edge_field<Q, false>(P, mo[j], 0.0, bo);  // what l saw of i's message at sweep t-1
                 double tot = 0.0;
+#if SBMBP_BATCH_RECIP
+                double rb[Q];
+                recip_all<Q>(bo, rb);
+#pragma unroll
+                for (int s = 0; s < Q; ++s) { inc[s] = pl[j][s] * rb[s]; tot += inc[s]; }
+#else
 #pragma unroll
                 for (int s = 0; s < Q; ++s) { inc[s] = pl[j][s] / bo[s]; tot += inc[s]; }
+#endif
                 const double inv = 1.0 / tot;
 #pragma unroll
                 for (int s = 0; s < Q; ++s) inc[s] *= inv;  // m^t_{l->i}
@@ -957,8 +985,15 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
             load_vec<Q>(&sA[r * Q], A);
             load_vec<Q>(&sb[le * Q], b);
             double tot = 0.0;
+#if SBMBP_BATCH_RECIP
+            double rb[Q];
+            recip_all<Q>(b, rb);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { cav[q] = A[q] * rb[q]; tot += cav[q]; }
+#else
 #pragma unroll
             for (int q = 0; q < Q; ++q) { cav[q] = A[q] / b[q]; tot += cav[q]; }
+#endif
             const double inv = 1.0 / tot;
             double ref[Q];
             if (exact) {  // uniform
@@ -1319,7 +1354,7 @@ template <int Q, bool DC2>
 __global__ void __launch_bounds__(FTPB)
 k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr, const uint32_t *__restrict__ ndeg /* degree of every table row (DC2 only) */,
            const double *__restrict__ M, const double *__restrict__ Min /* incoming messages in edge order, or null: gather M[rev] */,
-           const uint32_t *__restrict__ blk_row, const dev_params *__restrict__ P,
+           const uint32_t *__restrict__ blk_row, const uint32_t *__restrict__ blk_e0, const dev_params *__restrict__ P,
            int dc, int want_entropy, double *__restrict__ partials) {
     constexpr int EPT = frame_cfg<Q>::EPT, CAP = frame_cfg<Q>::CAP, RCAP = frame_cfg<Q>::RCAP;
     __shared__ double sb[CAP * Q];
@@ -1328,24 +1363,47 @@ k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
     __shared__ uint16_t srow[CAP];
     __shared__ double sred[FWAVES * (FE_NP + 1)];
     const int tid = threadIdx.x;
+    // as in the sweep kernels: segment bounds from one level of scalar loads, then every load of the lane-per-edge phase is
+    // issued branch-free and back to back (reverse index, own record, row offsets, then the gathers) before anything waits
     const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
     const int nrows = int(r1 - r0);
-    const uint32_t e0 = row_ptr[r0];
-    for (int r = tid; r <= nrows; r += FTPB) srp[r] = row_ptr[r0 + r] - e0;
-    __syncthreads();
-    const int ne = int(srp[nrows]);
+    const uint32_t e0 = blk_e0[blockIdx.x];
+    const int ne = int(blk_e0[blockIdx.x + 1] - e0);
     double acc[FE_NP] = {0.0, 0.0, 0.0, 0.0};
     if (ne <= CAP) {
-        for (int r = tid; r < nrows; r += FTPB)
-            for (int e = int(srp[r]); e < int(srp[r + 1]); ++e) srow[e] = uint16_t(r);
+        constexpr int RPT = RCAP / FTPB + 1;
+        uint32_t kk[EPT], rk[EPT], rpv[RPT];
+        double mo_[EPT][Q], mi_[EPT][Q];
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int le = j * FTPB + tid;
+            kk[j] = (ne > 0) ? e0 + uint32_t(le < ne ? le : 0) : 0u;
+        }
+        if (Min == nullptr) {  // uniform
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) rk[j] = rev[kk[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) load_msg<Q>(M, size_t(kk[j]), mo_[j]);
+#pragma unroll
+        for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; rpv[t] = row_ptr[r0 + uint32_t(r < nrows ? r : nrows)]; }
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) load_msg<Q>(Min ? Min : M, Min ? size_t(kk[j]) : size_t(rk[j]), mi_[j]);
+#pragma unroll
+        for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; if (r <= nrows) srp[r] = rpv[t] - e0; }
         __syncthreads();
+        if (DC2) {  // per-edge weights need the edge -> row map
+            for (int r = tid; r < nrows; r += FTPB)
+                for (int e = int(srp[r]); e < int(srp[r + 1]); ++e) srow[e] = uint16_t(r);
+            __syncthreads();
+        }
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
             const int le = j * FTPB + tid;
             if (le < ne) {
-                double mi[Q], mo[Q], b[Q];
-                load_msg<Q>(Min ? Min : M, Min ? size_t(e0 + le) : size_t(rev[e0 + le]), mi);
-                load_msg<Q>(M, size_t(e0 + le), mo);
+                double (&mi)[Q] = mi_[j];
+                double (&mo)[Q] = mo_[j];
+                double b[Q];
                 double didl = 0.0;
                 if (DC2) {
                     const int r = srow[le];
