@@ -299,8 +299,11 @@ def main():
         barrier()
         dtc = max_over_ranks(time.perf_counter() - t2)
         sweeps = niter + 1 if niter >= 0 else 1000
+        # overlap of the converged marginals with the planted labels (untimed): the device initial state and the sweeps are
+        # partition invariant, so `sweeps` and `overlap` of an N-GPU line must equal the 1-GPU line's
         converge = {"crit": CONV_CRIT, "sweeps": sweeps, "converged": niter >= 0, "wall_ms": dtc * 1e3,
-                    "edge_msg_per_s": sweeps * E2_total / dtc, "ms_per_sweep": dtc * 1e3 / sweeps}
+                    "edge_msg_per_s": sweeps * E2_total / dtc, "ms_per_sweep": dtc * 1e3 / sweeps,
+                    "overlap": runner.compute_overlap()}
 
     if rank == 0:
         kname = ("k_sweep_psi<%d>" if st.psi_form_sweeps else "k_sweep<%d>") % Q
