@@ -252,7 +252,21 @@ def main():
         # the ranks join the library's own RCCL communicators (torch.distributed only carried the id and, below, the
         # barriers around the timed regions); rehearsal: the same C++ driver with gloo between the processes
         from sbm_bp_amd.distributed import Comm, ShardedBP
-        comm = Comm.callbacks_from_torch() if rehearsal else Comm.rccl_from_torch(local_rank)
+        comm_note = None
+        if rehearsal:
+            comm = Comm.callbacks_from_torch()
+        else:
+            try:
+                comm, err = Comm.rccl_from_torch(local_rank), 0.0
+            except Exception as ex:  # noqa: BLE001 - whatever RCCL could not do on this node, the line must say so
+                comm, err, comm_note = None, 1.0, "RCCL communicator creation failed: %s" % ex
+            flag = torch.tensor([err], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)  # every rank takes the same branch
+            if float(flag.item()) > 0:
+                # last resort, so that the run still says something about this node: the same driver over gloo with the
+                # buffers staged through the host (the line names the transport; it is not the design's data path)
+                comm = Comm.callbacks_from_torch(group=dist.new_group(backend="gloo"))
+                comm_note = comm_note or "RCCL communicator creation failed on another rank"
         runner = ShardedBP.synthetic(N, Q, c, eps, gseed, dc=dc, seed=1234, comm=comm, device=local_rank)
         E2_total = runner.E2_global
 
@@ -333,6 +347,8 @@ def main():
             out["n_ranks_seen"] = runner.comm.world  # ranks of the communicator the sweeps ran on
             info = runner.info
             per_peer = runner.peer_rows()[0].astype(float) * info.halo_components * 8 / 1e6
+            if comm_note:
+                out["config"]["comm_fallback"] = comm_note
             out["config"]["exchange"] = {"transport": runner.comm.transport, "chunks": int(info.n_chunks),
                                          "payload_components": int(info.halo_components), "halo_rows": int(info.n_halo),
                                          "sent_MB_per_sweep": round(float(per_peer.sum()), 2),

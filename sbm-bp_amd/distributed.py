@@ -70,8 +70,8 @@ class Comm:
         return [cls(arr[r]) for r in range(world)]
 
     @classmethod
-    def callbacks_from_torch(cls):
-        """collectives of the default (gloo) process group on host buffers the library hands over"""
+    def callbacks_from_torch(cls, group=None):
+        """collectives of a gloo process group (default: the default group) on host buffers the library hands over"""
         import torch
         import torch.distributed as dist
         lib = load_library()
@@ -85,7 +85,7 @@ class Comm:
             try:
                 sc = [int(send_rows[p]) * width for p in range(world)]
                 rc = [int(recv_rows[p]) * width for p in range(world)]
-                dist.all_to_all_single(view(recv, sum(rc)), view(send, sum(sc)), rc, sc)
+                dist.all_to_all_single(view(recv, sum(rc)), view(send, sum(sc)), rc, sc, group=group)
                 return 0
             except Exception as ex:  # never let an exception cross the C boundary
                 print("exchange callback:", ex, flush=True)
@@ -94,7 +94,7 @@ class Comm:
         def allgather(user, inp, n, out):
             try:
                 parts = [torch.empty(int(n), dtype=torch.float64) for _ in range(world)]
-                dist.all_gather(parts, view(inp, n).clone())
+                dist.all_gather(parts, view(inp, n).clone(), group=group)
                 view(out, n * world).copy_(torch.cat(parts))
                 return 0
             except Exception as ex:
@@ -103,7 +103,7 @@ class Comm:
 
         def allreduce(user, buf, n, op):
             try:
-                dist.all_reduce(view(buf, n), op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
+                dist.all_reduce(view(buf, n), op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX, group=group)
                 return 0
             except Exception as ex:
                 print("allreduce callback:", ex, flush=True)
