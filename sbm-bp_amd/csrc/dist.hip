@@ -792,9 +792,25 @@ int run(sbmbp_dist *d, double crit, u32 max_sweeps, double damping, int *niter, 
     CHK(begin_run(d, crit, psi_ok, psi_ok && !first_explicit));
     u32 done = 0;
     sbmbp_conv_state cs{0.0, -1, 0, 0, 1};
-    bool near_end = false;
+    // batch sizes follow the decay of the reported difference (as run_sweeps of the single engine does): identical on every
+    // rank, because the state they are computed from is
+    const u32 batch_max = std::max<u32>(1, d->check_every);
+    u32 next_batch = batch_max;
+    double prev_md = -1.0;
+    int prev_idx = 0;
+    auto plan_next = [&](const sbmbp_conv_state &st) {
+        if (crit > 0 && prev_md > 0 && st.maxdiff > 0 && st.maxdiff < prev_md && st.sweep_idx > prev_idx) {
+            const double rate = std::pow(st.maxdiff / prev_md, 1.0 / double(st.sweep_idx - prev_idx));
+            const double need = st.maxdiff > crit ? std::ceil(std::log(crit / st.maxdiff) / std::log(rate)) : 1.0;
+            const double ahead = double(done) - double(st.sweep_idx);
+            next_batch = u32(std::min<double>(batch_max, std::max(1.0, need - ahead)));
+        } else {
+            next_batch = batch_max;
+        }
+        if (st.maxdiff > 0) { prev_md = st.maxdiff; prev_idx = st.sweep_idx; }
+    };
     auto queue_batch = [&](int slot) -> int {
-        const u32 batch = std::min(near_end ? 1u : std::max<u32>(1, d->check_every), max_sweeps - done);
+        const u32 batch = std::min(next_batch, max_sweeps - done);
         for (u32 b = 0; b < batch; ++b) {
             const u32 j = done + b;
             if (psi_ok && !(j == 0 && first_explicit)) CHK(queue_sweep_psi(d, j));
@@ -809,7 +825,7 @@ int run(sbmbp_dist *d, double crit, u32 max_sweeps, double damping, int *niter, 
             const bool more = done < max_sweeps;
             if (more) CHK(queue_batch((k + 1) & 1));
             CHK(sbmbp_shard_state_wait(d->eng, k & 1, &cs));
-            near_end = near_end || (crit > 0 && cs.maxdiff < 64.0 * crit);
+            plan_next(cs);
             if (cs.stop || !more) {
                 if (more) CHK(sbmbp_shard_state_wait(d->eng, (k + 1) & 1, &cs));  // drain the batch queued ahead (no-ops after a stop)
                 break;

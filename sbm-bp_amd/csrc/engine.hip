@@ -370,16 +370,31 @@ int run_sweeps(sbmbp_engine *e, double crit, uint32_t max_sweeps, double damping
     const bool first_from_psi = psi_ok && e->init_from_psi;
     const bool first_explicit = !e->psi_consistent && !first_from_psi;
     // Batches are queued one ahead: while the host waits for the convergence state of batch k, batch k+1 is already in
-    // the stream, so the GPU never idles at a batch boundary. Once exact mode is armed the end is near: batches shrink to
-    // one sweep, so at most one no-op sweep is left in the stream after the stop.
+    // the stream, so the GPU never idles at a batch boundary.
     if (!e->h_cs) {
         HIPCHK(hipHostMalloc(&e->h_cs, 2 * sizeof(conv_state), hipHostMallocDefault));
         for (auto &ev : e->ev_cs) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     conv_state *slots = static_cast<conv_state *>(e->h_cs);
-    bool near_end = false;
+    // Batch sizes follow the decay of the reported difference: from two readings the host estimates the rate per sweep and
+    // how many sweeps are still needed, and queues no more than that (minus what is already in the stream), so that only a
+    // sweep or two are left as no-ops behind the stop.
+    uint32_t next_batch = batch_max;
+    double prev_md = -1.0;
+    int prev_idx = 0;
+    auto plan_next = [&](const conv_state &st) {
+        if (crit > 0 && prev_md > 0 && st.maxdiff > 0 && st.maxdiff < prev_md && st.sweep_idx > prev_idx) {
+            const double rate = std::pow(st.maxdiff / prev_md, 1.0 / double(st.sweep_idx - prev_idx));
+            const double need = st.maxdiff > crit ? std::ceil(std::log(crit / st.maxdiff) / std::log(rate)) : 1.0;
+            const double ahead = double(done) - double(st.sweep_idx);  // queued, not yet seen
+            next_batch = uint32_t(std::min<double>(batch_max, std::max(1.0, need - ahead)));
+        } else {
+            next_batch = batch_max;
+        }
+        if (st.maxdiff > 0) { prev_md = st.maxdiff; prev_idx = st.sweep_idx; }
+    };
     auto queue_batch = [&](int slot) -> int {
-        const uint32_t batch = std::min(near_end ? 1u : batch_max, max_sweeps - done);
+        const uint32_t batch = std::min(next_batch, max_sweeps - done);
         for (uint32_t b = 0; b < batch; ++b) {
             const uint32_t j = done + b;
             const bool pf = psi_ok && !(j == 0 && first_explicit);
@@ -398,7 +413,7 @@ int run_sweeps(sbmbp_engine *e, double crit, uint32_t max_sweeps, double damping
             if (more) CHK(queue_batch((k + 1) & 1));
             HIPCHK(hipEventSynchronize(e->ev_cs[k & 1]));
             cs = slots[k & 1];
-            near_end = near_end || cs.exact != 0 || (crit > 0 && cs.maxdiff < 64.0 * crit);
+            plan_next(cs);
             if (cs.stop || !more) {
                 if (more) {  // drain the batch queued ahead (no-ops after a stop)
                     HIPCHK(hipEventSynchronize(e->ev_cs[(k + 1) & 1]));
