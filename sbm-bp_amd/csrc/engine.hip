@@ -162,7 +162,7 @@ const double *fold_stage(sbmbp_engine *e, uint32_t *rows, int ncols_sum, int has
     return e->d_stage;
 }
 
-inline int frame_cap(uint32_t Q) { return FTPB * (Q <= 2 ? SBMBP_EPT_LO : (Q <= 4 ? SBMBP_EPT_MID : (Q <= 8 ? SBMBP_EPT_HI : 1))); }
+inline int frame_cap(uint32_t Q) { return (Q <= 4 ? FTPB : SBMBP_FRAME_TPB_HI) * (Q <= 2 ? SBMBP_EPT_LO : (Q <= 4 ? SBMBP_EPT_MID : (Q <= 8 ? SBMBP_EPT_HI : 1))); }
 inline int frame_rcap(uint32_t Q) { const int cap = frame_cap(Q); return cap / 2 > 64 ? cap / 2 : 64; }
 
 // Q/dc dispatch over the templated kernels
@@ -280,21 +280,21 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form, bool f
     }
     if (psi_form) {
         if (clamp) {
-            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, true, false>), dim3(xcd_grid(e->n_blk)), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, true, false>), dim3(xcd_grid(e->n_blk)), dim3(frame_cfg<QQ>::TPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
                                                 Mnew, psi_old, psi_new, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), e->d_partials, clamp, shard_io{}, e->n_blk, SBMBP_XCD_REMAP,
                                                 Mold, int(first_from_psi)));
         } else {
-            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, false>), dim3(xcd_grid(e->n_blk)), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, false>), dim3(xcd_grid(e->n_blk)), dim3(frame_cfg<QQ>::TPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
                                                 Mnew, psi_old, psi_new, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), e->d_partials,
                                                 (const int32_t *)nullptr, shard_io{}, e->n_blk, SBMBP_XCD_REMAP,
                                                 Mold, int(first_from_psi)));
         }
     } else if (e->dc == 2) {
-        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, true>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, true>), dim3(e->n_blk), dim3(frame_cfg<QQ>::TPB), 0, e->stream, e->d_row_ptr,
                                             e->d_rev, e->d_nbr, e->d_deg, Mold, Mnew, psi_old, psi_new, clamp, e->d_blk_row, e->d_blk_e0, e->d_P,
                                             1, damp, e->d_partials));
     } else {
-        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, false>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, false>), dim3(e->n_blk), dim3(frame_cfg<QQ>::TPB), 0, e->stream, e->d_row_ptr,
                                             e->d_rev, e->d_nbr, e->d_deg, Mold, Mnew, psi_old, psi_new, clamp, e->d_blk_row, e->d_blk_e0, e->d_P,
                                             int(e->dc), damp, e->d_partials));
     }
@@ -482,14 +482,14 @@ int site_edge_terms(sbmbp_engine *e, bool want_entropy, double out[4], double *d
     const double *M = e->d_M[e->cur];
     const double *Min = (e->sharded && e->incoming_src == 0) ? e->d_Min : nullptr;
     if (e->dc == 2) {
-        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_frame<QQ, true>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_frame<QQ, true>), dim3(e->n_blk), dim3(frame_cfg<QQ>::TPB), 0, e->stream, e->d_row_ptr,
                                             e->d_rev, e->d_nbr, e->d_deg, M, Min, e->d_blk_row, e->d_blk_e0, e->d_P, 1, int(want_entropy), e->d_partials));
         if (e->n_hub)
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
                                                 e->d_rev, e->d_nbr, e->d_deg, M, Min, e->d_hub_row, e->d_hub_blk, e->d_P, 1,
                                                 int(want_entropy), e->d_partials));
     } else {
-        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_frame<QQ, false>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_frame<QQ, false>), dim3(e->n_blk), dim3(frame_cfg<QQ>::TPB), 0, e->stream, e->d_row_ptr,
                                             e->d_rev, e->d_nbr, e->d_deg, M, Min, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), int(want_entropy),
                                             e->d_partials));
         if (e->n_hub)
@@ -574,7 +574,7 @@ int nonedge_terms(sbmbp_engine *e, bool want_entropy, double out[2]) {
         HIPCHK(hipGetLastError());
         CHK(fold_to_host(e, g * g, NE_NP, NE_NP + 1, all));
         CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (NE_NP + 1)));
-        DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_exact_adj<QQ>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
+        DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_exact_adj<QQ>), dim3(e->n_blk), dim3(frame_cfg<QQ>::TPB), 0, e->stream, e->d_row_ptr,
                                          e->d_nbr, e->d_psi[e->pcur], d_Pm, d_cab, e->d_blk_row, invN, int(want_entropy),
                                          e->d_partials));
         HIPCHK(hipGetLastError());
@@ -612,7 +612,7 @@ int nonedge_terms(sbmbp_engine *e, bool want_entropy, double out[2]) {
             off += tsz;
         }
         CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (NE_NP + 1)));
-        DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_adj<QQ>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr,
+        DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_adj<QQ>), dim3(e->n_blk), dim3(frame_cfg<QQ>::TPB), 0, e->stream, e->d_row_ptr,
                                          e->d_nbr, e->d_psi[e->pcur], d_w, d_cab, e->d_blk_row, invN, int(want_entropy), e->d_partials));
         HIPCHK(hipGetLastError());
         CHK(fold_to_host(e, e->n_blk, NE_NP, NE_NP + 1, adj));
@@ -1582,10 +1582,10 @@ int sbmbp_shard_sweep_explicit(sbmbp_engine_t *e, uint32_t j, double damping) {
     }
     if (e->n_blk) {
         if (e->dc == 2) {
-            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, true>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_rev, e->d_nbr,
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, true>), dim3(e->n_blk), dim3(frame_cfg<QQ>::TPB), 0, e->stream, e->d_row_ptr, e->d_rev, e->d_nbr,
                                                 e->d_deg, Mold, Mnew, psi_old, psi_new, clamp, e->d_blk_row, e->d_blk_e0, e->d_P, 1, damping, e->d_partials));
         } else {
-            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, false>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_rev, e->d_nbr,
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep<QQ, false>), dim3(e->n_blk), dim3(frame_cfg<QQ>::TPB), 0, e->stream, e->d_row_ptr, e->d_rev, e->d_nbr,
                                                 e->d_deg, Mold, Mnew, psi_old, psi_new, clamp, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), damping, e->d_partials));
         }
     }
@@ -1744,11 +1744,11 @@ int sbmbp_shard_sweep_chunk_on(sbmbp_engine_t *e, uint32_t j, uint32_t c, void *
     if (nb)
     {
         if (io.snd_ptr) {
-            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, true>), dim3(shard_xcd ? xcd_grid(nb) : nb), dim3(FTPB), 0, stream, e->d_row_ptr, e->d_nbr, Mio,
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, true>), dim3(shard_xcd ? xcd_grid(nb) : nb), dim3(frame_cfg<QQ>::TPB), 0, stream, e->d_row_ptr, e->d_nbr, Mio,
                                                 psi_old, psi_new, e->d_blk_row + b0, e->d_blk_e0 + b0, e->d_P, int(e->dc),
                                                 e->d_partials + size_t(b0) * (e->Q + 1), (const int32_t *)nullptr, io, nb, shard_xcd, Mcmp, first));
         } else {
-            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, false>), dim3(nb), dim3(FTPB), 0, stream, e->d_row_ptr, e->d_nbr, Mio,
+            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi<QQ, false, false>), dim3(nb), dim3(frame_cfg<QQ>::TPB), 0, stream, e->d_row_ptr, e->d_nbr, Mio,
                                                 psi_old, psi_new, e->d_blk_row + b0, e->d_blk_e0 + b0, e->d_P, int(e->dc),
                                                 e->d_partials + size_t(b0) * (e->Q + 1), (const int32_t *)nullptr, io, nb, 0, Mcmp, first));
         }
@@ -1935,7 +1935,7 @@ int sbmbp_shard_nonedge_partial(sbmbp_engine_t *e, int want_entropy, uint32_t *n
     HIPCHK(hipGetLastError());
     CHK(fold_matrix_to_device(e, nb, uint32_t(T), e->d_red));
     CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (NE_NP + 1)));
-    DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_adj<QQ>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
+    DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_adj<QQ>), dim3(e->n_blk), dim3(frame_cfg<QQ>::TPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
                                      e->d_psi[e->pcur], e->d_mats, e->d_mats + 2 * Q * Q, e->d_blk_row, 1.0 / double(e->Nglob),
                                      want_entropy, e->d_partials));
     HIPCHK(hipGetLastError());
@@ -1970,7 +1970,7 @@ int sbmbp_shard_nonedge_exact_partial(sbmbp_engine_t *e, const double *d_psi_all
     HIPCHK(hipGetLastError());
     CHK(fold_to_device(e, gi * gl, NE_NP, NE_NP + 1, e->d_red));
     CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (NE_NP + 1)));
-    DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_exact_adj<QQ>), dim3(e->n_blk), dim3(FTPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
+    DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_exact_adj<QQ>), dim3(e->n_blk), dim3(frame_cfg<QQ>::TPB), 0, e->stream, e->d_row_ptr, e->d_nbr,
                                      e->d_psi[e->pcur], d_Pm, d_cab, e->d_blk_row, invN, want_entropy, e->d_partials));
     HIPCHK(hipGetLastError());
     CHK(fold_to_device(e, e->n_blk, NE_NP, NE_NP + 1, e->d_red + 2));

@@ -33,6 +33,7 @@ struct dev_params {
     double etaF[QMAX];         // eta[q] * exp(-beta h[q]/N)   (dc 0 field factor)
     double S[QMAX];            // sum_i g_i psi_i[q] after relaxation (h = cab^T S)
     double beta, invN, field_mix, crit;
+    double prev_hint;          // 2-step hint of the sweep before (0: none): its ratio to the current one estimates the rate
     double maxdiff;            // of the last executed sweep
     int conv_iter;             // -1 until the first sweep with maxdiff < crit
     int sweep_idx;             // sweeps executed in the current converge call
@@ -47,10 +48,12 @@ struct dev_params {
     int last_exact;            // maxdiff of the last executed sweep is a 1-step difference (not a hint)
     int pad_;
 };
-// With linear convergence at rate r the 2-step difference is (1 + 1/r) times the 1-step one, so exact mode is armed at
-// HINT_SCALE * crit: the first sweep whose 1-step difference is below crit is then already an exact-mode sweep unless
-// r < 1/(HINT_SCALE - 1), and the returned niter equals the explicit form's.
-constexpr double HINT_SCALE = 8.0;
+// With linear convergence at rate r the 2-step difference of sweep t is (1 + 1/r) times its 1-step difference d_t, and the
+// sweep BEFORE the first one with d_t < crit has a hint below crit (1 + 1/r) / r. The exact criterion must be armed by then, so
+// it is armed at scale * crit with scale = 1.5 (1 + 1/r) / r from the measured ratio of consecutive hints, kept within
+// [HINT_SCALE, HINT_SCALE_MAX]: slowly converging runs (r >= 0.5: the large graphs) pay the extra read for 3-4 sweeps only,
+// fast ones arm earlier, and the returned niter equals the message-gather form's unless r < 0.15.
+constexpr double HINT_SCALE = 8.0, HINT_SCALE_MAX = 64.0;
 
 // tunables (A/B'd on MI355X, see DESIGN.md "Tuning log")
 #ifndef SBMBP_EPT_LO
@@ -74,14 +77,17 @@ constexpr double HINT_SCALE = 8.0;
 #ifndef SBMBP_FRAME_TPB
 #define SBMBP_FRAME_TPB 256  // threads per workgroup of the frame kernels (multiple of 64)
 #endif
+#ifndef SBMBP_FRAME_TPB_HI
+#define SBMBP_FRAME_TPB_HI 128  // ... above Q = 4 (A/B on C4, Q = 8: 0.492 -> 0.472 ms; neutral on the Q <= 4 workloads, which keep 256)
+#endif
 constexpr int FTPB = SBMBP_FRAME_TPB;
 // launch grid of the marginal-gather sweep for n segments (padded for the XCD mapping)
 inline uint32_t xcd_grid(uint32_t n) { return SBMBP_XCD_REMAP ? 8u * ((n + 7u) / 8u) : n; }
-constexpr int FWAVES = FTPB / 64;
-
 template <int Q> struct frame_cfg {
+    static constexpr int TPB = (Q <= 4) ? FTPB : SBMBP_FRAME_TPB_HI;  // threads per workgroup
+    static constexpr int WAVES = TPB / 64;
     static constexpr int EPT = (Q <= 2) ? SBMBP_EPT_LO : (Q <= 4 ? SBMBP_EPT_MID : (Q <= 8 ? SBMBP_EPT_HI : 1));  // directed edges per lane
-    static constexpr int CAP = FTPB * EPT;                 // edges per workgroup segment
+    static constexpr int CAP = TPB * EPT;                  // edges per workgroup segment
     static constexpr int RCAP = (CAP / 2 > 64) ? CAP / 2 : 64;  // rows per workgroup segment
 };
 
@@ -519,7 +525,7 @@ __device__ __forceinline__ void edge_field(const dev_params *__restrict__ P, con
 // partials[b*(Q+1) + q] = sum_rows g_i psi_i[q],  partials[b*(Q+1)+Q] = max |delta message|.
 // ------------------------------------------------------------------------------------------------
 template <int Q, bool DC2>
-__global__ void __launch_bounds__(FTPB)
+__global__ void __launch_bounds__(frame_cfg<Q>::TPB)
 k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr, const uint32_t *__restrict__ ndeg /* degree of every table row (DC2 only) */,
         const double *__restrict__ Mold, double *__restrict__ Mnew, const double *__restrict__ psi_old,
         double *__restrict__ psi, const int32_t *__restrict__ clamp, const uint32_t *__restrict__ blk_row,
@@ -530,7 +536,7 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
     __shared__ uint32_t srp[RCAP + 1]; // row offsets relative to the segment
     __shared__ uint16_t srow[CAP];     // row (within segment) of every edge
     __shared__ uint8_t sfl[RCAP];      // 1 = clamped row
-    __shared__ double sred[FWAVES * (Q + 1)];
+    __shared__ double sred[frame_cfg<Q>::WAVES * (Q + 1)];
     __shared__ int sbig;               // the segment holds a row above BIG_ROW edges
 
     // bounds and stop flag from one level of scalar loads; streams issued before the row offsets -> LDS fill
@@ -543,12 +549,12 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
 
     // ---- phase 1: lane per directed edge: gather incoming message, b = W^T m -> LDS (branch-free loads,
     // see k_sweep_psi)
-    constexpr int RPT = RCAP / FTPB + 1;
+    constexpr int RPT = RCAP / frame_cfg<Q>::TPB + 1;
     double mo[EPT][Q];
     uint32_t rk[EPT], kk[EPT];
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
-        const int le = j * FTPB + tid;
+        const int le = j * frame_cfg<Q>::TPB + tid;
         kk[j] = (ne > 0) ? e0 + uint32_t(le < ne ? le : 0) : 0u;
     }
 #pragma unroll
@@ -557,15 +563,15 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
     for (int j = 0; j < EPT; ++j) load_msg_stream<Q>(Mold, kk[j], mo[j]);
     uint32_t rpv[RPT];
 #pragma unroll
-    for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; rpv[t] = row_ptr[r0 + uint32_t(r < nrows ? r : nrows)]; }
+    for (int t = 0; t < RPT; ++t) { const int r = tid + t * frame_cfg<Q>::TPB; rpv[t] = row_ptr[r0 + uint32_t(r < nrows ? r : nrows)]; }
     double mi[EPT][Q];
 #pragma unroll
     for (int j = 0; j < EPT; ++j) load_msg<Q>(Mold, rk[j], mi[j]);
     if (tid == 0) sbig = 0;
 #pragma unroll
-    for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; if (r <= nrows) srp[r] = rpv[t] - e0; }
+    for (int t = 0; t < RPT; ++t) { const int r = tid + t * frame_cfg<Q>::TPB; if (r <= nrows) srp[r] = rpv[t] - e0; }
     __syncthreads();  // srp visible
-    for (int r = tid; r < nrows; r += FTPB) {
+    for (int r = tid; r < nrows; r += frame_cfg<Q>::TPB) {
         const int es = int(srp[r]), ee = int(srp[r + 1]);
         if (ee - es > BIG_ROW) sbig = 1;
         for (int e = es; e < ee; ++e) srow[e] = uint16_t(r);
@@ -574,7 +580,7 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
     if (DC2) __syncthreads();  // per-edge weights need the edge -> row map
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
-        const int le = j * FTPB + tid;
+        const int le = j * frame_cfg<Q>::TPB + tid;
         if (le < ne) {
             double didl = 0.0;
             if (DC2) {
@@ -612,7 +618,7 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
         for (int q = 0; q < Q; ++q) { pv[q] = A[q] * inv; Sacc[q] += gi * pv[q]; }
         store_vec<Q>(psi + size_t(r0 + r) * Q, pv);
     };
-    for (int r = tid; r < nrows; r += FTPB) {
+    for (int r = tid; r < nrows; r += frame_cfg<Q>::TPB) {
         const int es = int(srp[r]), ee = int(srp[r + 1]);
         const double di = double(ee - es);
         if (sfl[r]) {  // clamped: marginal and out-messages stay as initialised (bp.cpp:1115-1124)
@@ -637,7 +643,7 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
         }
     }
     if (sbig)  // uniform: written before the barrier that ends phase 1
-    for (int r = tid >> 6; r < nrows; r += FWAVES) {  // wave-uniform row index
+    for (int r = tid >> 6; r < nrows; r += frame_cfg<Q>::WAVES) {  // wave-uniform row index
         const int es = int(srp[r]), ee = int(srp[r + 1]);
         if (ee - es > BIG_ROW && !sfl[r]) {
             double A[Q];
@@ -652,7 +658,7 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
     double md = 0.0;
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
-        const int le = j * FTPB + tid;
+        const int le = j * frame_cfg<Q>::TPB + tid;
         if (le < ne) {
             const int r = srow[le];
             double out[Q];
@@ -696,7 +702,7 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
             store_msg_stream<Q>(Mnew, size_t(e0 + le), out);
         }
     }
-    block_reduce_store<Q, FWAVES>(Sacc, md, sred, partials + size_t(blockIdx.x) * (Q + 1));
+    block_reduce_store<Q, frame_cfg<Q>::WAVES>(Sacc, md, sred, partials + size_t(blockIdx.x) * (Q + 1));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -748,9 +754,9 @@ template <int Q> __device__ __forceinline__ void send_row(const shard_io &io, ui
 template <int Q, bool CLAMP, bool SHARD>
 __global__ void
 #if SBMBP_PSI_WAVES > 0
-__launch_bounds__(FTPB, SBMBP_PSI_WAVES)
+__launch_bounds__(frame_cfg<Q>::TPB, SBMBP_PSI_WAVES)
 #else
-__launch_bounds__(FTPB)
+__launch_bounds__(frame_cfg<Q>::TPB)
 #endif
 k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, double *__restrict__ Mio,
             const double *__restrict__ psi_old, double *__restrict__ psi_new, const uint32_t *__restrict__ blk_row,
@@ -765,7 +771,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     __shared__ double sA[RCAP * Q];
     __shared__ uint32_t srp[RCAP + 1];
     __shared__ uint16_t srow[CAP];
-    __shared__ double sred[FWAVES * (Q + 1)];
+    __shared__ double sred[frame_cfg<Q>::WAVES * (Q + 1)];
     __shared__ int sbig;  // the segment holds a row above BIG_ROW edges
     __shared__ uint8_t sfl[CLAMP ? RCAP : 1];  // 1 = clamped row
     constexpr int SLOTS = SHARD ? 4 * RCAP : 1;          // send slots of the segment's rows kept in LDS (the rest from HBM)
@@ -799,12 +805,12 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     // ---- phase 1: lane per directed edge. Loads are branch-free (inactive lanes re-read the segment's first
     // edge) so the compiler issues them back to back: index stream, own-message stream, row offsets (kept in
     // registers), then the gathers as soon as the indices are back — no LDS write or wait in between.
-    constexpr int RPT = RCAP / FTPB + 1;
+    constexpr int RPT = RCAP / frame_cfg<Q>::TPB + 1;
     double mo[EPT][Q];
     uint32_t nl[EPT], kk[EPT];
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
-        const int le = j * FTPB + tid;
+        const int le = j * frame_cfg<Q>::TPB + tid;
         kk[j] = (ne > 0) ? e0 + uint32_t(le < ne ? le : 0) : 0u;
     }
 #pragma unroll
@@ -813,10 +819,10 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     for (int j = 0; j < EPT; ++j) load_msg_stream<Q>(Mio, kk[j], mo[j]);
     uint32_t rpv[RPT], spv[RPT];
 #pragma unroll
-    for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; rpv[t] = row_ptr[r0 + uint32_t(r < nrows ? r : nrows)]; }
+    for (int t = 0; t < RPT; ++t) { const int r = tid + t * frame_cfg<Q>::TPB; rpv[t] = row_ptr[r0 + uint32_t(r < nrows ? r : nrows)]; }
     if (SHARD) {  // the rows' send-slot offsets travel with the row offsets; the slots themselves follow after the barrier
 #pragma unroll
-        for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; spv[t] = io.snd_ptr[r0 + uint32_t(r < nrows ? r : nrows)]; }
+        for (int t = 0; t < RPT; ++t) { const int r = tid + t * frame_cfg<Q>::TPB; spv[t] = io.snd_ptr[r0 + uint32_t(r < nrows ? r : nrows)]; }
     }
     double pl[EPT][Q];
 #pragma unroll
@@ -842,19 +848,19 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     }
     if (tid == 0) sbig = 0;
 #pragma unroll
-    for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; if (r <= nrows) srp[r] = rpv[t] - e0; }
+    for (int t = 0; t < RPT; ++t) { const int r = tid + t * frame_cfg<Q>::TPB; if (r <= nrows) srp[r] = rpv[t] - e0; }
     uint32_t s0 = 0;
     if (SHARD) {
         s0 = io.snd_ptr[r0];
 #pragma unroll
-        for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; if (r <= nrows) ssp[r] = spv[t] - s0; }
+        for (int t = 0; t < RPT; ++t) { const int r = tid + t * frame_cfg<Q>::TPB; if (r <= nrows) ssp[r] = spv[t] - s0; }
     }
     __syncthreads();  // srp (and ssp) visible
     if (SHARD) {  // issue the slot loads now; they are consumed after the next barriers
         const uint32_t ns = min(ssp[nrows], uint32_t(SLOTS));
-        for (uint32_t x = tid; x < ns; x += FTPB) sslot[x] = io.snd_slot[s0 + x];
+        for (uint32_t x = tid; x < ns; x += frame_cfg<Q>::TPB) sslot[x] = io.snd_slot[s0 + x];
     }
-    for (int r = tid; r < nrows; r += FTPB) {
+    for (int r = tid; r < nrows; r += frame_cfg<Q>::TPB) {
         const int es = int(srp[r]), ee = int(srp[r + 1]);
         if (ee - es > BIG_ROW) sbig = 1;
         for (int e = es; e < ee; ++e) srow[e] = uint16_t(r);
@@ -862,7 +868,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     }
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
-        const int le = j * FTPB + tid;
+        const int le = j * frame_cfg<Q>::TPB + tid;
         if (le < ne) {
             double bo[Q], inc[Q], b[Q];
             if (first_from_psi) {  // uniform
@@ -929,7 +935,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
 #endif
         }
     };
-    for (int r = tid; r < nrows; r += FTPB) {
+    for (int r = tid; r < nrows; r += frame_cfg<Q>::TPB) {
         const int es = int(srp[r]), ee = int(srp[r + 1]);
         if (CLAMP && sfl[r]) {
             double pv[Q];
@@ -953,7 +959,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
         }
     }
     if (sbig)  // uniform: written before the barrier that ends phase 1
-    for (int r = tid >> 6; r < nrows; r += FWAVES) {  // wave-uniform row index
+    for (int r = tid >> 6; r < nrows; r += frame_cfg<Q>::WAVES) {  // wave-uniform row index
         const int es = int(srp[r]), ee = int(srp[r + 1]);
         if (ee - es > BIG_ROW && !(CLAMP && sfl[r])) {
             double A[Q];
@@ -966,7 +972,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
 #ifndef SBMBP_DEBUG_NOSEND
     if (SHARD) {  // send pass: one lane per send slot, stores in flight while phase 3 runs
         const uint32_t ns = min(ssp[nrows], uint32_t(SLOTS));
-        for (uint32_t x = tid; x < ns; x += FTPB) {
+        for (uint32_t x = tid; x < ns; x += frame_cfg<Q>::TPB) {
             const double *src = &sA[int(ssrow[x]) * Q];
             double *dst = io.sendbuf + size_t(sslot[x]) * io.ncomp;
 #pragma unroll
@@ -978,7 +984,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     // ---- phase 3: lane per directed edge: cavity, normalise, overwrite own slot
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
-        const int le = j * FTPB + tid;
+        const int le = j * frame_cfg<Q>::TPB + tid;
         if (le < ne && !(CLAMP && sfl[srow[le]])) {
             const int r = srow[le];
             double A[Q], b[Q], cav[Q], out[Q];
@@ -1010,7 +1016,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
             store_msg_stream<Q>(Mio, size_t(e0 + le), out);
         }
     }
-    block_reduce_store<Q, FWAVES>(Sacc, md, sred, partials + size_t(bid) * (Q + 1));
+    block_reduce_store<Q, frame_cfg<Q>::WAVES>(Sacc, md, sred, partials + size_t(bid) * (Q + 1));
 }
 
 // K1ph: marginal-gather form of the hub-row update (one workgroup per row with degree > CAP)
@@ -1307,7 +1313,13 @@ k_finalize(const double *__restrict__ partials, uint32_t n_part, int Q, int mode
             const bool is_hint = P->hinted && !P->exact && !md_exact;
             P->last_exact = is_hint ? 0 : 1;
             if (is_hint) {  // a 2-step hint: it can only arm the exact criterion
-                if (md < HINT_SCALE * P->crit) P->exact = 1;
+                double scale = HINT_SCALE;
+                if (P->prev_hint > 0.0 && md > 0.0 && md < P->prev_hint) {
+                    const double r = md / P->prev_hint;
+                    scale = fmin(HINT_SCALE_MAX, fmax(HINT_SCALE, 1.5 * (1.0 + 1.0 / r) / r));
+                }
+                P->prev_hint = md;
+                if (md < scale * P->crit) P->exact = 1;
             } else if (md < P->crit && P->conv_iter < 0) {
                 P->conv_iter = it;
                 P->stop = 1;
@@ -1351,7 +1363,7 @@ __device__ __forceinline__ void edge_terms(const dev_params *__restrict__ P, con
 }
 
 template <int Q, bool DC2>
-__global__ void __launch_bounds__(FTPB)
+__global__ void __launch_bounds__(frame_cfg<Q>::TPB)
 k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr, const uint32_t *__restrict__ ndeg /* degree of every table row (DC2 only) */,
            const double *__restrict__ M, const double *__restrict__ Min /* incoming messages in edge order, or null: gather M[rev] */,
            const uint32_t *__restrict__ blk_row, const uint32_t *__restrict__ blk_e0, const dev_params *__restrict__ P,
@@ -1361,7 +1373,7 @@ k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
     __shared__ double sc[CAP * Q];  // entropy: b with plain cab weights (no beta)
     __shared__ uint32_t srp[RCAP + 1];
     __shared__ uint16_t srow[CAP];
-    __shared__ double sred[FWAVES * (FE_NP + 1)];
+    __shared__ double sred[frame_cfg<Q>::WAVES * (FE_NP + 1)];
     const int tid = threadIdx.x;
     // as in the sweep kernels: segment bounds from one level of scalar loads, then every load of the lane-per-edge phase is
     // issued branch-free and back to back (reverse index, own record, row offsets, then the gathers) before anything waits
@@ -1371,12 +1383,12 @@ k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
     const int ne = int(blk_e0[blockIdx.x + 1] - e0);
     double acc[FE_NP] = {0.0, 0.0, 0.0, 0.0};
     if (ne <= CAP) {
-        constexpr int RPT = RCAP / FTPB + 1;
+        constexpr int RPT = RCAP / frame_cfg<Q>::TPB + 1;
         uint32_t kk[EPT], rk[EPT], rpv[RPT];
         double mo_[EPT][Q], mi_[EPT][Q];
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
-            const int le = j * FTPB + tid;
+            const int le = j * frame_cfg<Q>::TPB + tid;
             kk[j] = (ne > 0) ? e0 + uint32_t(le < ne ? le : 0) : 0u;
         }
         if (Min == nullptr) {  // uniform
@@ -1386,20 +1398,20 @@ k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
 #pragma unroll
         for (int j = 0; j < EPT; ++j) load_msg<Q>(M, size_t(kk[j]), mo_[j]);
 #pragma unroll
-        for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; rpv[t] = row_ptr[r0 + uint32_t(r < nrows ? r : nrows)]; }
+        for (int t = 0; t < RPT; ++t) { const int r = tid + t * frame_cfg<Q>::TPB; rpv[t] = row_ptr[r0 + uint32_t(r < nrows ? r : nrows)]; }
 #pragma unroll
         for (int j = 0; j < EPT; ++j) load_msg<Q>(Min ? Min : M, Min ? size_t(kk[j]) : size_t(rk[j]), mi_[j]);
 #pragma unroll
-        for (int t = 0; t < RPT; ++t) { const int r = tid + t * FTPB; if (r <= nrows) srp[r] = rpv[t] - e0; }
+        for (int t = 0; t < RPT; ++t) { const int r = tid + t * frame_cfg<Q>::TPB; if (r <= nrows) srp[r] = rpv[t] - e0; }
         __syncthreads();
         if (DC2) {  // per-edge weights need the edge -> row map
-            for (int r = tid; r < nrows; r += FTPB)
+            for (int r = tid; r < nrows; r += frame_cfg<Q>::TPB)
                 for (int e = int(srp[r]); e < int(srp[r + 1]); ++e) srow[e] = uint16_t(r);
             __syncthreads();
         }
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
-            const int le = j * FTPB + tid;
+            const int le = j * frame_cfg<Q>::TPB + tid;
             if (le < ne) {
                 double (&mi)[Q] = mi_[j];
                 double (&mo)[Q] = mo_[j];
@@ -1430,7 +1442,7 @@ k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
             }
         }
         __syncthreads();
-        for (int r = tid; r < nrows; r += FTPB) {
+        for (int r = tid; r < nrows; r += frame_cfg<Q>::TPB) {
             const int es = int(srp[r]), ee = int(srp[r + 1]);
             const double di = double(ee - es);
             double A[Q];
@@ -1459,7 +1471,7 @@ k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
             }
         }
     }
-    block_reduce_store<FE_NP, FWAVES>(acc, 0.0, sred, partials + size_t(blockIdx.x) * (FE_NP + 1));
+    block_reduce_store<FE_NP, frame_cfg<Q>::WAVES>(acc, 0.0, sred, partials + size_t(blockIdx.x) * (FE_NP + 1));
 }
 
 template <int Q, bool DC2>
@@ -1527,23 +1539,24 @@ k_fe_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev,
 // ------------------------------------------------------------------------------------------------
 constexpr int NE_NP = 2;
 template <int Q>
-__global__ void __launch_bounds__(FTPB)
+__global__ void __launch_bounds__(frame_cfg<Q>::TPB)
 k_nonedge_adj(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, const double *__restrict__ psi,
               const double *__restrict__ wmat /* Q*Q: N(1-(1-cab/N)^beta) */, const double *__restrict__ cab,
               const uint32_t *__restrict__ blk_row, double invN, int want_entropy, double *__restrict__ partials) {
-    __shared__ double sred[FWAVES * (NE_NP + 1)];
+    __shared__ double sred[frame_cfg<Q>::WAVES * (NE_NP + 1)];
     __shared__ uint32_t srp[frame_cfg<Q>::RCAP + 1];
     const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
     const int nrows = int(r1 - r0);
     const uint32_t e0 = row_ptr[r0];
     __shared__ double sclc[Q * Q];  // cab log cab, once per workgroup instead of Q*Q logs per edge
-    for (int r = threadIdx.x; r <= nrows; r += FTPB) srp[r] = row_ptr[r0 + r] - e0;
-    if (want_entropy && threadIdx.x < Q * Q) sclc[threadIdx.x] = cab[threadIdx.x] * log(cab[threadIdx.x]);
+    for (int r = threadIdx.x; r <= nrows; r += frame_cfg<Q>::TPB) srp[r] = row_ptr[r0 + r] - e0;
+    if (want_entropy)
+        for (int x = threadIdx.x; x < Q * Q; x += frame_cfg<Q>::TPB) sclc[x] = cab[x] * log(cab[x]);
     __syncthreads();
     const int ne = int(srp[nrows]);
     double acc[NE_NP] = {0.0, 0.0};
     // lane per directed edge; the row of an edge is found by binary search in the LDS offsets
-    for (int le = threadIdx.x; le < ne; le += FTPB) {
+    for (int le = threadIdx.x; le < ne; le += frame_cfg<Q>::TPB) {
         int lo = 0, hi = nrows;  // find r with srp[r] <= le < srp[r+1]
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (int(srp[mid]) <= le) lo = mid; else hi = mid; }
         double pi[Q], pl[Q];
@@ -1566,7 +1579,7 @@ k_nonedge_adj(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__
         acc[0] += log1p(-y * invN);
         if (want_entropy) acc[1] += (u * invN) / (1.0 - yc * invN);
     }
-    block_reduce_store<NE_NP, FWAVES>(acc, 0.0, sred, partials + size_t(blockIdx.x) * (NE_NP + 1));
+    block_reduce_store<NE_NP, frame_cfg<Q>::WAVES>(acc, 0.0, sred, partials + size_t(blockIdx.x) * (NE_NP + 1));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1737,22 +1750,23 @@ k_nonedge_exact(const double *__restrict__ psi /* rows i: n of them (a shard: it
 
 // exact per-edge terms to subtract from the all-pairs sums of k_nonedge_exact
 template <int Q>
-__global__ void __launch_bounds__(FTPB)
+__global__ void __launch_bounds__(frame_cfg<Q>::TPB)
 k_nonedge_exact_adj(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, const double *__restrict__ psi,
                     const double *__restrict__ Pmat, const double *__restrict__ cab, const uint32_t *__restrict__ blk_row,
                     double invN, int want_entropy, double *__restrict__ partials) {
-    __shared__ double sred[FWAVES * (NE_NP + 1)];
+    __shared__ double sred[frame_cfg<Q>::WAVES * (NE_NP + 1)];
     __shared__ uint32_t srp[frame_cfg<Q>::RCAP + 1];
     const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
     const int nrows = int(r1 - r0);
     const uint32_t e0 = row_ptr[r0];
     __shared__ double sclc[Q * Q];  // (cab/N) log cab, once per workgroup
-    for (int r = threadIdx.x; r <= nrows; r += FTPB) srp[r] = row_ptr[r0 + r] - e0;
-    if (want_entropy && threadIdx.x < Q * Q) sclc[threadIdx.x] = (cab[threadIdx.x] * invN) * log(cab[threadIdx.x]);
+    for (int r = threadIdx.x; r <= nrows; r += frame_cfg<Q>::TPB) srp[r] = row_ptr[r0 + r] - e0;
+    if (want_entropy)
+        for (int x = threadIdx.x; x < Q * Q; x += frame_cfg<Q>::TPB) sclc[x] = (cab[x] * invN) * log(cab[x]);
     __syncthreads();
     const int ne = int(srp[nrows]);
     double acc[NE_NP] = {0.0, 0.0};
-    for (int le = threadIdx.x; le < ne; le += FTPB) {
+    for (int le = threadIdx.x; le < ne; le += frame_cfg<Q>::TPB) {
         int lo = 0, hi = nrows;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (int(srp[mid]) <= le) lo = mid; else hi = mid; }
         double pi[Q], pl[Q];
@@ -1775,7 +1789,7 @@ k_nonedge_exact_adj(const uint32_t *__restrict__ row_ptr, const uint32_t *__rest
         if (f != 0.0) acc[0] += log(f);
         if (want_entropy && num * den != 0.0) acc[1] += num / den;
     }
-    block_reduce_store<NE_NP, FWAVES>(acc, 0.0, sred, partials + size_t(blockIdx.x) * (NE_NP + 1));
+    block_reduce_store<NE_NP, frame_cfg<Q>::WAVES>(acc, 0.0, sred, partials + size_t(blockIdx.x) * (NE_NP + 1));
 }
 
 // ------------------------------------------------------------------------------------------------

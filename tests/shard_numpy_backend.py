@@ -47,6 +47,7 @@ class NumpyShardBackend:
     def begin(self, crit):
         self.crit = crit
         self.exact = False
+        self.prev_hint = 0.0
         self.st = State()
 
     def set_schedule(self, field_mix, check_every=1):
@@ -135,8 +136,13 @@ class NumpyShardBackend:
             md = float(rows[:, self.Q].max())
             self.st.maxdiff = md
             self.st.last_exact = int(self.exact)
-            if not self.exact:  # a 2-step hint can only arm the exact criterion (k_finalize, HINT_SCALE = 8)
-                if md < 8.0 * self.crit:
+            if not self.exact:  # a 2-step hint can only arm the exact criterion (k_finalize: scale from the measured rate)
+                scale, prev = 8.0, getattr(self, "prev_hint", 0.0)
+                if prev > 0.0 and 0.0 < md < prev:
+                    r = md / prev
+                    scale = min(64.0, max(8.0, 1.5 * (1.0 + 1.0 / r) / r))
+                self.prev_hint = md
+                if md < scale * self.crit:
                     self.exact = True
             elif md < self.crit and self.st.conv_iter < 0:
                 self.st.conv_iter, self.st.stop = self.st.sweep_idx, 1
