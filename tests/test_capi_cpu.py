@@ -188,3 +188,32 @@ def test_synthetic_generator(S):
     tc = synth.true_conf(40000, 4)
     same = (tc[pairs[:, 0]] == tc[pairs[:, 1]]).mean()
     assert abs(same - cin / (cin + 3 * cout)) < 0.01
+
+
+def test_communicator_handles_and_no_device_errors():
+    """the host side of the multi-GPU layer without a GPU: in-process and null communicators are plain host objects; creating
+    a rank's engine without a device fails loudly (no CPU fallback), as does an RCCL communicator"""
+    import ctypes as C
+    import torch
+    import sbm_bp_amd as S
+    from sbm_bp_amd.capi import COMM_ID_BYTES
+    lib = S.load_library()
+    arr = (C.c_void_p * 3)()
+    assert lib.sbmbp_comm_init_local(arr, 3) == 0
+    assert [lib.sbmbp_comm_rank(arr[r]) for r in range(3)] == [0, 1, 2] and lib.sbmbp_comm_size(arr[1]) == 3
+    assert lib.sbmbp_comm_transport(arr[0]) == b"local"
+    lib.sbmbp_comm_abort(arr[2])  # a rank gives up: the group is marked failed, nobody would block on it
+    h = C.c_void_p()
+    assert lib.sbmbp_comm_init_null(C.byref(h), 8, 5) == 0 and lib.sbmbp_comm_rank(h) == 5 and lib.sbmbp_comm_transport(h) == b"null"
+    assert lib.sbmbp_comm_init_null(C.byref(C.c_void_p()), 4, 4) != 0  # rank outside the communicator
+    if not torch.cuda.is_available():
+        g = S.Graph.from_edges(np.array([[0, 1], [1, 2], [2, 3]], dtype=np.uint32), 4)
+        d = C.c_void_p()
+        rc = lib.sbmbp_dist_create(C.byref(d), h, g._h, 2, 0, 0, 0)
+        assert rc == -3 and b"no CPU fallback" in lib.sbmbp_last_error()
+        assert lib.sbmbp_device_count() == 0
+        c2 = C.c_void_p()
+        assert lib.sbmbp_comm_init_rank(C.byref(c2), bytes(COMM_ID_BYTES), 1, 0, 0) == -3
+    lib.sbmbp_comm_destroy(h)
+    for r in range(3):
+        lib.sbmbp_comm_destroy(arr[r])
