@@ -13,7 +13,7 @@ for WL in C3 C2 C4 C5; do
   else python3 bench.py --workload $WL --no-cpu-baseline --converge > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err || exit 1; fi
   tail -c 600 $OUT/bench_$WL.json >&2
   echo "== rocprofv3 stats $WL" >&2
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$WL -o run -- python3 bench.py --workload $WL --no-cpu-baseline > $OUT/stats_$WL.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$WL -o run -- python3 bench.py --workload $WL --no-cpu-baseline --no-converge > $OUT/stats_$WL.log 2>&1 || exit 1
 done
 echo "== bench C3 --gather messages" >&2
 python3 bench.py --workload C3 --no-cpu-baseline --gather messages > $OUT/bench_C3_messages.json 2> $OUT/bench_C3_messages.err || exit 1
