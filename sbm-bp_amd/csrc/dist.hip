@@ -965,7 +965,8 @@ int sbmbp_dist_create(sbmbp_dist_t **out, sbmbp_comm_t *comm, const sbmbp_graph_
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device visible; the engine has no CPU fallback"); return SBMBP_ERR_NODEVICE; }
     if (device >= 0) HIPCHK(hipSetDevice(device));
-    std::unique_ptr<sbmbp_dist> d(new sbmbp_dist());
+    // (a failure half way frees what exists so far: sbmbp_dist_destroy copes with a partly built object)
+    std::unique_ptr<sbmbp_dist, void (*)(sbmbp_dist *)> d(new sbmbp_dist(), sbmbp_dist_destroy);
     HIPCHK(hipGetDevice(&d->device));
     d->comm = comm;
     d->graph = g;
