@@ -39,6 +39,9 @@ WORKLOADS = {
     "C3x10": (100_000_000, 4, 10.0, 0.1, 0, 2),
     # degree-corrected SBM, power-law propensities, --deg_corr_flag 1 (hub rows take the workgroup-per-row kernel)
     "C4": (1_000_000, 8, 8.0, 0.1, 1, 3),
+    # the same Q and mean degree as C4 on a plain planted partition (Poisson degrees): separates what Q = 8 costs from what the
+    # power-law degrees cost
+    "Q8": (1_000_000, 8, 8.0, 0.1, 0, 3),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 CONV_CRIT = 5e-6       # the reference's default -e (main.cpp:113)

@@ -58,6 +58,13 @@ struct sbmbp_engine {
     uint64_t n_halo_msgs = 0;      // shards: message records received from peers, kept behind the own records (rev points there)
     int incoming_src = 0;          // shards, reductions: 0 = incoming messages materialised from the marginals, 1 = gathered through rev
     uint32_t *d_blk_row = nullptr, *d_blk_e0 = nullptr, *d_hub_row = nullptr, *d_hub_blk = nullptr, *d_true = nullptr;
+    // hub rows cut into fragments of BLOCK edges (marginal-gather sweep: k_hub_frag_product / k_hub_frag_cavity)
+    uint32_t *d_frag_hub = nullptr, *d_hub_frag0 = nullptr;
+    double *d_hub_b = nullptr, *d_hub_pA = nullptr;
+    int *d_hub_pE = nullptr;
+    uint32_t n_frag = 0;
+    std::vector<uint32_t> h_hub_frag0;  // [n_hub + 1]
+    uint32_t *d_fold_counters = nullptr;  // arrival counter of k_fold_finalize (zero between launches)
     int32_t *d_clamp = nullptr;
     uint32_t n_blk = 0, n_hub = 0;
     hipStream_t hub_stream = nullptr;  // hub rows (one workgroup each, latency-bound) run beside the frame kernel
@@ -216,6 +223,42 @@ int upload_params(sbmbp_engine *e, double crit, bool hinted = false) {
     return SBMBP_OK;
 }
 
+// Fragment tables of the hub rows (kernels.h: hub_frags): hub h owns fragments hub_frag0[h] .. hub_frag0[h+1], of BLOCK
+// edges each (the last one shorter). The edge-field scratch costs 8 Q bytes per hub edge, rounded up to whole fragments.
+int setup_hub_frags(sbmbp_engine *e, const std::vector<uint32_t> &hub_row, const std::vector<uint32_t> &rp32) {
+    std::vector<uint32_t> frag_hub;
+    e->h_hub_frag0.assign(1, 0u);
+    for (size_t h = 0; h < hub_row.size(); ++h) {
+        const uint32_t d = rp32[hub_row[h] + 1] - rp32[hub_row[h]];
+        for (uint32_t k = 0; k < (d + BLOCK - 1) / BLOCK; ++k) frag_hub.push_back(uint32_t(h));
+        e->h_hub_frag0.push_back(uint32_t(frag_hub.size()));
+    }
+    e->n_frag = uint32_t(frag_hub.size());
+    if (!e->n_frag) return SBMBP_OK;
+    CHK(dev_alloc(e, &e->d_frag_hub, frag_hub.size()));
+    CHK(dev_alloc(e, &e->d_hub_frag0, e->h_hub_frag0.size()));
+    CHK(dev_alloc(e, &e->d_hub_b, size_t(e->n_frag) * BLOCK * e->Q));
+    CHK(dev_alloc(e, &e->d_hub_pA, size_t(e->n_frag) * e->Q));
+    CHK(dev_alloc(e, &e->d_hub_pE, size_t(e->n_frag) * e->Q));
+    HIPCHK(hipMemcpyAsync(e->d_frag_hub, frag_hub.data(), frag_hub.size() * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_hub_frag0, e->h_hub_frag0.data(), e->h_hub_frag0.size() * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));  // frag_hub is a local
+    return SBMBP_OK;
+}
+
+// marginal-gather update of hub rows [h0, h0 + nh): two launches over their fragments
+int launch_hub_psi(sbmbp_engine *e, hipStream_t st, uint32_t h0, uint32_t nh, double *Mio, const double *psi_old, double *psi_new,
+                   const int32_t *clamp, const shard_io &io, const double *Mcmp, int first) {
+    if (!nh) return SBMBP_OK;
+    const uint32_t f0 = e->h_hub_frag0[h0], nf = e->h_hub_frag0[h0 + nh] - f0;
+    const hub_frags hf{e->d_frag_hub, e->d_hub_frag0, e->d_hub_b, e->d_hub_pA, e->d_hub_pE};
+    DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_hub_frag_product<QQ>), dim3(nf), dim3(BLOCK), 0, st, e->d_row_ptr, e->d_nbr, Mio, psi_old,
+                                        e->d_hub_row, e->d_hub_blk, hf, f0, e->d_P, e->d_partials, clamp, io, first));
+    DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_hub_frag_cavity<QQ>), dim3(nf), dim3(BLOCK), 0, st, e->d_row_ptr, Mio, psi_old, psi_new,
+                                        e->d_hub_row, e->d_hub_blk, hf, f0, e->d_P, int(e->dc), e->d_partials, clamp, io, Mcmp));
+    return SBMBP_OK;
+}
+
 // h from the current psi (init_h, bp.cpp:320-332); mode 1 = converge start, 2 = exact refresh
 int launch_field(sbmbp_engine *e, int mode) {
     const uint32_t rows_per_blk = 4096;
@@ -223,8 +266,8 @@ int launch_field(sbmbp_engine *e, int mode) {
     CHK(ensure_partials(e, size_t(nb) * (e->Q + 1)));
     DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_psi_sum<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_psi[e->pcur],
                                         e->N, rows_per_blk, int(e->dc != 0), e->d_partials));
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, e->stream, e->d_partials, nb, int(e->Q), mode, e->d_P,
-                       (double *)nullptr, 0u, 0);
+    DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_finalize<QQ>), dim3(1), dim3(BLOCK), 0, e->stream, e->d_partials, nb, mode, e->d_P,
+                                        (double *)nullptr, 0u, 0));
     HIPCHK(hipGetLastError());
     return SBMBP_OK;
 }
@@ -241,20 +284,24 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form, bool f
     const int32_t *clamp = e->has_clamp ? e->d_clamp : nullptr;
     // hub rows first, on their own stream: a few hundred long-running workgroups that overlap with the frame kernel
     // (disjoint rows and edges; both only read psi_old and the parameter block)
+    // Hub rows. Marginal-gather form: fragment kernels on the sweep's own stream (they are throughput-bound like the frame
+    // kernel: beside it on a second stream they gained nothing, C4 0.545 vs 0.533 ms per sweep). Message-gather form: one
+    // workgroup per hub row, latency-bound, on their own stream beside the frame kernel.
+    const bool hub_serial = psi_form;
     if (e->n_hub) {
-        if (!e->hub_stream) {
+        if (!hub_serial && !e->hub_stream) {
             HIPCHK(hipStreamCreateWithFlags(&e->hub_stream, hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
         }
-        hipStream_t hs = e->hub_stream;
-        HIPCHK(hipEventRecord(e->ev_fork, e->stream));
-        HIPCHK(hipStreamWaitEvent(hs, e->ev_fork, 0));
-        if (e->n_hub && psi_form) {
-            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi_hub<QQ>), dim3(e->n_hub), dim3(BLOCK), 0, hs, e->d_row_ptr,
-                                                e->d_nbr, Mnew, psi_old, psi_new, e->d_hub_row, e->d_hub_blk, e->d_P,
-                                                int(e->dc), e->d_partials, clamp, shard_io{}, Mold, int(first_from_psi)));
-        } else if (e->n_hub) {
+        hipStream_t hs = hub_serial ? e->stream : e->hub_stream;
+        if (!hub_serial) {
+            HIPCHK(hipEventRecord(e->ev_fork, e->stream));
+            HIPCHK(hipStreamWaitEvent(hs, e->ev_fork, 0));
+        }
+        if (psi_form) {
+            CHK(launch_hub_psi(e, hs, 0, e->n_hub, Mnew, psi_old, psi_new, clamp, shard_io{}, Mold, int(first_from_psi)));
+        } else {
             if (e->dc == 2) {
                 DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, hs,
                                                     e->d_row_ptr, e->d_rev, e->d_nbr, e->d_deg, Mold, Mnew, psi_old, psi_new, clamp,
@@ -265,7 +312,7 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form, bool f
                                                     e->d_hub_row, e->d_hub_blk, e->d_P, int(e->dc), damp, e->d_partials));
             }
         }
-        HIPCHK(hipEventRecord(e->ev_join, hs));
+        if (!hub_serial) HIPCHK(hipEventRecord(e->ev_join, hs));
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (e->timing) {
@@ -299,11 +346,17 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form, bool f
                                             int(e->dc), damp, e->d_partials));
     }
     if (e->timing) HIPCHK(hipEventRecord(e1, e->stream));
-    if (e->n_hub) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
-    uint32_t rows = e->n_blk;
-    const double *part = fold_stage(e, &rows, int(e->Q), 1, e->Q + 1);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, e->stream, part, rows, int(e->Q), 0, e->d_P,
-                       e->d_hist, e->hist_cap, int(!psi_form));
+    if (e->n_hub && !hub_serial) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+    // fold of the segment records + K2 in one launch (k_fold_finalize): <= FOLD_BLOCKS workgroups of >= 2048 records each
+    if (!e->d_fold_counters) {
+        CHK(dev_alloc(e, &e->d_fold_counters, 1));
+        HIPCHK(hipMemsetAsync(e->d_fold_counters, 0, 4, e->stream));
+    }
+    const uint32_t rows = e->n_blk;
+    const uint32_t nb = std::min<uint32_t>(FOLD_BLOCKS, std::max<uint32_t>(1, (rows + 2047) / 2048));
+    const uint32_t chunk = (rows + nb - 1) / nb;
+    DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fold_finalize<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_partials, rows, chunk, e->d_P, e->d_hist,
+                                        e->hist_cap, int(!psi_form), e->d_stage, e->d_fold_counters));
     HIPCHK(hipGetLastError());
     return SBMBP_OK;
 }
@@ -901,6 +954,8 @@ int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint3
     e->hist_cap = 4096;
     TRY(dev_alloc(e, &e->d_hist, e->hist_cap));
     TRY(ensure_partials(e, size_t(e->n_blk) * (QMAX + 1)));
+    TRY(dev_alloc(e, &e->d_fold_counters, 1));
+    TRYHIP(hipMemsetAsync(e->d_fold_counters, 0, 4, e->stream));
     TRY(ensure_small(e, 8192));
     TRY(dev_alloc(e, &e->d_stage, size_t(FOLD_BLOCKS) * FOLD_STRIDE_MAX));
     TRYHIP(hipMemcpyAsync(e->d_row_ptr, rp32.data(), rp32.size() * 4, hipMemcpyHostToDevice, e->stream));
@@ -918,6 +973,7 @@ int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint3
     if (e->n_hub) {
         TRYHIP(hipMemcpyAsync(e->d_hub_row, hub_row.data(), hub_row.size() * 4, hipMemcpyHostToDevice, e->stream));
         TRYHIP(hipMemcpyAsync(e->d_hub_blk, hub_blk.data(), hub_blk.size() * 4, hipMemcpyHostToDevice, e->stream));
+        TRY(setup_hub_frags(e, hub_row, rp32));
     }
     TRYHIP(hipMemsetAsync(e->d_true, 0, size_t(e->N) * 4, e->stream));
     TRYHIP(hipMemsetAsync(e->d_clamp, 0xff, size_t(e->N) * 4, e->stream));
@@ -950,7 +1006,7 @@ void sbmbp_destroy(sbmbp_engine_t *e) {
     if (e->ext_psi) e->d_psi[0] = e->d_psi[1] = nullptr;  // caller-owned
     void *ptrs[] = {e->d_deg, e->d_row_ptr, e->d_rev, e->d_nbr, e->d_src, e->d_blk_row, e->d_blk_e0, e->d_hub_row, e->d_hub_blk, e->d_true,
                     e->d_clamp, e->d_M[0], e->d_M[1], e->d_psi[0], e->d_psi[1], e->d_Min, e->d_snd_ptr, e->d_snd_slot, e->d_P, e->d_partials, e->d_small, e->d_hist, e->d_mats,
-                    e->d_stage};
+                    e->d_stage, e->d_frag_hub, e->d_hub_frag0, e->d_hub_b, e->d_hub_pA, e->d_hub_pE, e->d_fold_counters};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto ev : e->ev) hipEventDestroy(ev);
     if (e->h_cs) (void)hipHostFree(e->h_cs);
@@ -1491,6 +1547,7 @@ int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *d, uint32_t
     if (e->n_hub) {
         TRYHIP(hipMemcpyAsync(e->d_hub_row, hub_row.data(), hub_row.size() * 4, hipMemcpyHostToDevice, e->stream));
         TRYHIP(hipMemcpyAsync(e->d_hub_blk, hub_blk.data(), hub_blk.size() * 4, hipMemcpyHostToDevice, e->stream));
+        TRY(setup_hub_frags(e, hub_row, rp32));
     }
     TRYHIP(hipMemsetAsync(e->d_true, 0, size_t(e->N) * 4, e->stream));
     TRYHIP(hipMemsetAsync(e->d_partials, 0, e->partials_cap * 8, e->stream));
@@ -1754,10 +1811,7 @@ int sbmbp_shard_sweep_chunk_on(sbmbp_engine_t *e, uint32_t j, uint32_t c, void *
         }
     }
     if (e->timing && nb) HIPCHK(hipEventRecord(e1, stream));
-    if (nh)
-        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_psi_hub<QQ>), dim3(nh), dim3(BLOCK), 0, stream, e->d_row_ptr,
-                                            e->d_nbr, Mio, psi_old, psi_new, e->d_hub_row + h0, e->d_hub_blk + h0, e->d_P,
-                                            int(e->dc), e->d_partials, (const int32_t *)nullptr, io, Mcmp, first));
+    CHK(launch_hub_psi(e, stream, h0, nh, Mio, psi_old, psi_new, (const int32_t *)nullptr, io, Mcmp, first));
     HIPCHK(hipGetLastError());
     return SBMBP_OK;
 }
@@ -1786,7 +1840,7 @@ int sbmbp_shard_finalize(sbmbp_engine_t *e, int mode, uint32_t n_rows, int md_ex
     device_scope dev_(e);
     IS_SHARD(e);
     if ((mode != 0 && mode != 1) || n_rows == 0 || n_rows > 64u * SBMBP_FOLD_ROWS) return SBMBP_ERR_ARG;
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, e->stream, e->d_red + SBMBP_RED_GATHER_OFFSET, n_rows, int(e->Q), mode, e->d_P, e->d_hist, e->hist_cap, md_exact);
+    DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_finalize<QQ>), dim3(1), dim3(BLOCK), 0, e->stream, e->d_red + SBMBP_RED_GATHER_OFFSET, n_rows, mode, e->d_P, e->d_hist, e->hist_cap, md_exact));
     HIPCHK(hipGetLastError());
     return SBMBP_OK;
 }

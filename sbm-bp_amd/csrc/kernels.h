@@ -720,6 +720,64 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
 // difference the reference's criterion uses is measured by k_msg_diff before convergence is declared
 // (so a period-2 oscillation, whose 2-step difference vanishes, can never pass as converged).
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// K2 (one lane): the folded sums S[q] and the maximum difference of a sweep -> relaxed field, h / eta exp(-beta h),
+// convergence state. mode 0: after a sweep; mode 1: field initialisation (no sweep bookkeeping); mode 2: exact field
+// refresh (no relaxation, no bookkeeping).
+// ------------------------------------------------------------------------------------------------
+// Everything is loaded before anything is stored (P may alias nothing else here, but the compiler cannot know that the
+// stores to P do not change what the later loads from P return): one memory round trip instead of a chain of them. With a
+// run-time Q and local arrays indexed by it the same code lived in scratch memory and took 6 (Q = 2) to 21 us (Q = 8).
+template <int Q>
+__device__ __forceinline__ void finalize_update(dev_params *__restrict__ P, const double *sums /* [Q] then the max */, int mode,
+                                                double *__restrict__ diff_hist, uint32_t hist_cap, int md_exact) {
+    double cab[Q * Q], eta[Q], Sold[Q], S[Q];
+#pragma unroll
+    for (int a = 0; a < Q * Q; ++a) cab[a] = P->cab[a];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { eta[q] = P->eta[q]; Sold[q] = P->S[q]; }
+    const double mix = P->field_mix, invN = P->invN, beta = P->beta, crit = P->crit, prev_hint = P->prev_hint;
+    const int have_prev = P->have_prev, hinted = P->hinted, exact = P->exact, conv_iter = P->conv_iter, it = P->sweep_idx;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        double s = sums[q];
+        if (mode == 0 && have_prev && mix < 1.0) s = (1.0 - mix) * Sold[q] + mix * s;
+        S[q] = s;
+    }
+    double hN[Q], etaF[Q];
+#pragma unroll
+    for (int q1 = 0; q1 < Q; ++q1) {  // h[q1] = sum_q2 cab[q2][q1] S[q2]   (bp.cpp:341-355)
+        double h = 0.0;
+#pragma unroll
+        for (int q2 = 0; q2 < Q; ++q2) h += cab[q2 * Q + q1] * S[q2];
+        hN[q1] = h * invN;
+        etaF[q1] = eta[q1] * exp(-beta * hN[q1]);
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { P->S[q] = S[q]; P->hN[q] = hN[q]; P->etaF[q] = etaF[q]; }
+    P->have_prev = 1;
+    if (mode == 0) {
+        const double md = sums[Q];
+        P->maxdiff = md;
+        if (diff_hist != nullptr && uint32_t(it) < hist_cap) diff_hist[it] = md;
+        const bool is_hint = hinted && !exact && !md_exact;
+        P->last_exact = is_hint ? 0 : 1;
+        if (is_hint) {  // a 2-step hint: it can only arm the exact criterion
+            double scale = HINT_SCALE;
+            if (prev_hint > 0.0 && md > 0.0 && md < prev_hint) {
+                const double r = md / prev_hint;
+                scale = fmin(HINT_SCALE_MAX, fmax(HINT_SCALE, 1.5 * (1.0 + 1.0 / r) / r));
+            }
+            P->prev_hint = md;
+            if (md < scale * crit) P->exact = 1;
+        } else if (md < crit && conv_iter < 0) {
+            P->conv_iter = it;
+            P->stop = 1;
+        }
+        P->sweep_idx = it + 1;
+    }
+}
+
 // Shard mode of the marginal-gather sweep: halo marginals are gathered straight from the receive buffer the exchange
 // filled (rows of ncomp = Q-1 or Q components; the halo is numbered in receive order, plan.py), and a freshly computed
 // marginal is dropped into every send slot that ships it, so the sweep needs no pack and no unpack kernel around it.
@@ -800,7 +858,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     const uint32_t r0 = blk_row[bid], r1 = blk_row[bid + 1];
     const uint32_t e0 = blk_e0[bid];
     const int nrows = int(r1 - r0), ne = int(blk_e0[bid + 1] - e0);
-    if (stop || ne > CAP) return;  // stopped run, or hub row (k_sweep_psi_hub owns it): uniform exit before any barrier
+    if (stop || ne > CAP) return;  // stopped run, or hub row (the fragment kernels own it): uniform exit before any barrier
 
     // ---- phase 1: lane per directed edge. Loads are branch-free (inactive lanes re-read the segment's first
     // edge) so the compiler issues them back to back: index stream, own-message stream, row offsets (kept in
@@ -1019,95 +1077,169 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     block_reduce_store<Q, frame_cfg<Q>::WAVES>(Sacc, md, sred, partials + size_t(bid) * (Q + 1));
 }
 
-// K1ph: marginal-gather form of the hub-row update (one workgroup per row with degree > CAP)
+// product of the workgroup's per-lane partial products, every lane returning the result: shuffle butterfly inside
+// the waves (both partners of a step compute the same bits: a*b == b*a), then the wave results in wave order
+template <int Q, int WAVES> __device__ __forceinline__ void block_product_shfl(double (&A)[Q], int (&ae)[Q], double *sAw, int *sEw) {
+    x_norm<Q>(A, ae);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { A[q] *= __shfl_xor(A[q], o, 64); ae[q] += __shfl_xor(ae[q], o, 64); }
+        x_norm<Q>(A, ae);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { sAw[wave * Q + q] = A[q]; sEw[wave * Q + q] = ae[q]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { A[q] = sAw[q]; ae[q] = sEw[q]; }
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { A[q] *= sAw[w * Q + q]; ae[q] += sEw[w * Q + q]; }
+        x_norm<Q>(A, ae);
+    }
+}
+
+// K1ph: marginal-gather form of the hub-row update (rows with degree > CAP), in FRAGMENTS of BLOCK edges.
+// One workgroup per hub row is a latency chain as long as the row (neighbour index -> its marginal, per 256 edges, twice),
+// the sweep waits for the longest row, and a degree-1e5 hub of a large power-law graph would run for milliseconds: measured
+// on C4 (1106 hub rows holding 8 % of the edges, longest 2494) that kernel took 0.14 ms alone, a third of the frame kernel
+// with 92 % of the edges. So a hub row is cut into fragments of BLOCK edges and updated by two short launches over all
+// fragments of all hub rows: k_hub_frag_product (the edge fields of the fragment, kept in hub_b, and their product),
+// k_hub_frag_cavity (the row product from the fragment products, the new marginal, the cavities of the fragment's edges).
+// Every workgroup of a row multiplies the same fragment products in the same order, so they agree bitwise on the row
+// product. The maximum message difference of the fragments meets in the row's partial record through atomicMax on the bit
+// pattern (differences are >= 0 or NaN, and a NaN pattern is above every number: order-independent, so reproducible).
+struct hub_frags {
+    const uint32_t *frag_hub;   // [n_frag] hub index of the fragment
+    const uint32_t *hub_frag0;  // [n_hub + 1] first fragment of the hub
+    double *b;                  // [n_frag * BLOCK][Q] edge fields between the two launches
+    double *pA;                 // [n_frag][Q] fragment products: mantissas ...
+    int *pE;                    // ... and binary exponents
+};
 template <int Q>
 __global__ void __launch_bounds__(BLOCK)
-k_sweep_psi_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, double *__restrict__ Mio,
-                const double *__restrict__ psi_old, double *__restrict__ psi_new, const uint32_t *__restrict__ hub_row,
-                const uint32_t *__restrict__ hub_blk, const dev_params *__restrict__ P, int dc,
-                double *__restrict__ partials, const int32_t *__restrict__ clamp, shard_io io,
-                const double *__restrict__ Mcmp, int first_from_psi) {
+k_hub_frag_product(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, const double *__restrict__ Mio,
+                   const double *__restrict__ psi_old, const uint32_t *__restrict__ hub_row, const uint32_t *__restrict__ hub_blk,
+                   hub_frags hf, uint32_t frag_first, const dev_params *__restrict__ P, double *__restrict__ partials,
+                   const int32_t *__restrict__ clamp, shard_io io, int first_from_psi) {
+    if (P->stop) return;
+    __shared__ double sAw[(BLOCK / 64) * Q];
+    __shared__ int sEw[(BLOCK / 64) * Q];
+    const int tid = threadIdx.x;
+    const uint32_t f = frag_first + blockIdx.x, h = hf.frag_hub[f], k = f - hf.hub_frag0[h];
+    const uint32_t i = hub_row[h];
+    const uint32_t e0 = row_ptr[i], d = row_ptr[i + 1] - e0;
+    if (k == 0 && tid == 0) partials[size_t(hub_blk[h]) * (Q + 1) + Q] = 0.0;  // the row's difference record: the fragments max into it
+    if (clamp != nullptr && clamp[i] != -1) return;  // clamped hub (uniform): nothing to multiply
+    const uint32_t le = k * BLOCK + tid;
+    const bool ok = le < d;
+    const uint32_t lc = ok ? le : d - 1;  // branch-free loads; the slot is masked below
+    const uint32_t l = nbr[e0 + lc];
+    double pl[Q], mo[Q], inc[Q], b[Q];
+    if (io.halo_stage != nullptr && l >= io.n_own) load_halo_row<Q>(io, l - io.n_own, pl);
+    else load_vec<Q>(psi_old + size_t(l) * Q, pl);
+    if (first_from_psi) {  // uniform
+#pragma unroll
+        for (int s = 0; s < Q; ++s) inc[s] = pl[s];
+    } else {
+        double bo[Q];
+        load_msg<Q>(Mio, size_t(e0 + lc), mo);
+        edge_field<Q, false>(P, mo, 0.0, bo);
+        double tot = 0.0;
+#pragma unroll
+        for (int s = 0; s < Q; ++s) { inc[s] = pl[s] / bo[s]; tot += inc[s]; }
+        const double inv = 1.0 / tot;
+#pragma unroll
+        for (int s = 0; s < Q; ++s) inc[s] *= inv;
+    }
+    edge_field<Q, false>(P, inc, 0.0, b);
+    if (ok) store_vec<Q>(hf.b + (size_t(f) * BLOCK + tid) * Q, b);
+    double A[Q];
+    int ae[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { A[q] = ok ? b[q] : 1.0; ae[q] = 0; }
+    block_product_shfl<Q, BLOCK / 64>(A, ae, sAw, sEw);
+    if (tid == 0) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { hf.pA[size_t(f) * Q + q] = A[q]; hf.pE[size_t(f) * Q + q] = ae[q]; }
+    }
+}
+template <int Q>
+__global__ void __launch_bounds__(BLOCK)
+k_hub_frag_cavity(const uint32_t *__restrict__ row_ptr, double *__restrict__ Mio, const double *__restrict__ psi_old,
+                  double *__restrict__ psi_new, const uint32_t *__restrict__ hub_row, const uint32_t *__restrict__ hub_blk,
+                  hub_frags hf, uint32_t frag_first, const dev_params *__restrict__ P, int dc, double *__restrict__ partials,
+                  const int32_t *__restrict__ clamp, shard_io io, const double *__restrict__ Mcmp) {
     if (P->stop) return;
     const int exact = P->exact;
-    __shared__ double sAq[BLOCK * Q];
-    __shared__ int sEq[BLOCK * Q];
-    __shared__ double sred[4 * (Q + 1)];
+    __shared__ double sAw[(BLOCK / 64) * Q];
+    __shared__ int sEw[(BLOCK / 64) * Q];
+    __shared__ double smd[BLOCK / 64];
     const int tid = threadIdx.x;
-    const uint32_t i = hub_row[blockIdx.x];
+    const uint32_t f = frag_first + blockIdx.x, h = hf.frag_hub[f], f0 = hf.hub_frag0[h], nf = hf.hub_frag0[h + 1] - f0;
+    const uint32_t i = hub_row[h];
     const uint32_t e0 = row_ptr[i], d = row_ptr[i + 1] - e0;
     const double di = double(d);
-    double Sacc[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) Sacc[q] = 0.0;
-    double md = 0.0;
+    double *rec = partials + size_t(hub_blk[h]) * (Q + 1);
     if (clamp != nullptr && clamp[i] != -1) {  // clamped hub (uniform): marginal copied, messages stay
-        if (tid == 0) {
+        if (f == f0 && tid == 0) {
             double pv[Q];
             load_vec<Q>(psi_old + size_t(i) * Q, pv);
             store_vec<Q>(psi_new + size_t(i) * Q, pv);
 #pragma unroll
-            for (int q = 0; q < Q; ++q) Sacc[q] = (dc ? di : 1.0) * pv[q];
+            for (int q = 0; q < Q; ++q) rec[q] = (dc ? di : 1.0) * pv[q];
         }
-        block_reduce_store<Q>(Sacc, md, sred, partials + size_t(hub_blk[blockIdx.x]) * (Q + 1));
         return;
     }
     double A[Q];
     int ae[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) { A[q] = 1.0; ae[q] = 0; }
-    auto incoming_field = [&](uint32_t le, double (&mo)[Q], double (&b)[Q]) {
-        double pl[Q], bo[Q], inc[Q];
-        const uint32_t l = nbr[e0 + le];
-        if (io.halo_stage != nullptr && l >= io.n_own) load_halo_row<Q>(io, l - io.n_own, pl);
-        else load_vec<Q>(psi_old + size_t(l) * Q, pl);
-        load_msg<Q>(Mio, size_t(e0 + le), mo);
-        if (first_from_psi) {  // uniform
+    for (uint32_t x = tid; x < nf; x += BLOCK) {
 #pragma unroll
-            for (int s = 0; s < Q; ++s) inc[s] = pl[s];
-        } else {
-            edge_field<Q, false>(P, mo, 0.0, bo);
-            double tot = 0.0;
-#pragma unroll
-            for (int s = 0; s < Q; ++s) { inc[s] = pl[s] / bo[s]; tot += inc[s]; }
-            const double inv = 1.0 / tot;
-#pragma unroll
-            for (int s = 0; s < Q; ++s) inc[s] *= inv;
-        }
-        edge_field<Q, false>(P, inc, 0.0, b);
-    };
-    for (uint32_t le = tid; le < d; le += BLOCK) {
-        double mo[Q], b[Q];
-        incoming_field(le, mo, b);
-#pragma unroll
-        for (int q = 0; q < Q; ++q) A[q] *= b[q];
+        for (int q = 0; q < Q; ++q) { A[q] *= hf.pA[size_t(f0 + x) * Q + q]; ae[q] += hf.pE[size_t(f0 + x) * Q + q]; }
         x_norm<Q>(A, ae);
     }
-    block_product_x<Q>(A, ae, sAq, sEq);
+    block_product_shfl<Q, BLOCK / 64>(A, ae, sAw, sEw);
     const double tot = apply_field_x<Q>(P, dc, di, A, ae);
     const double inv = 1.0 / tot;
-    if (tid == 0) {
+    if (f == f0 && tid == 0) {
         double pv[Q];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) { pv[q] = A[q] * inv; Sacc[q] = (dc ? di : 1.0) * pv[q]; }
+        for (int q = 0; q < Q; ++q) { pv[q] = A[q] * inv; rec[q] = (dc ? di : 1.0) * pv[q]; }
         store_vec<Q>(psi_new + size_t(i) * Q, pv);
         if (io.snd_ptr != nullptr) send_row<Q>(io, i, pv);
     }
-    for (uint32_t le = tid; le < d; le += BLOCK) {
-        double mo[Q], b[Q], out[Q], cav[Q];
-        incoming_field(le, mo, b);
+    double md = 0.0;
+    const uint32_t le = (f - f0) * BLOCK + tid;
+    if (le < d) {
+        double b[Q], ref[Q], out[Q], cav[Q];
+        load_vec<Q>(hf.b + (size_t(f) * BLOCK + tid) * Q, b);
+        load_msg<Q>(exact ? Mcmp : Mio, size_t(e0 + le), ref);  // exact 1-step difference, else the 2-step hint
         double ct = 0.0;
 #pragma unroll
         for (int q = 0; q < Q; ++q) { cav[q] = A[q] / b[q]; ct += cav[q]; }
         const double ci = 1.0 / ct;
-        if (exact) load_msg<Q>(Mcmp, size_t(e0 + le), mo);  // exact 1-step difference instead of the 2-step hint
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             out[q] = cav[q] * ci;
-            md = nanmax(md, fabs(mo[q] - out[q]));
+            md = nanmax(md, fabs(ref[q] - out[q]));
         }
         store_msg<Q>(Mio, size_t(e0 + le), out);
     }
-    block_reduce_store<Q>(Sacc, md, sred, partials + size_t(hub_blk[blockIdx.x]) * (Q + 1));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) md = nanmax(md, __shfl_xor(md, o, 64));
+    if ((tid & 63) == 0) smd[tid >> 6] = md;
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int w = 1; w < BLOCK / 64; ++w) md = nanmax(md, smd[w]);
+        atomicMax(reinterpret_cast<unsigned long long *>(rec + Q), (unsigned long long)__double_as_longlong(fabs(md)));
+    }
 }
 
 // gather rows idx[0..n) of a [rows][Q] table into a contiguous buffer (halo send packing). With
@@ -1267,66 +1399,69 @@ k_psi_sum(const uint32_t *__restrict__ row_ptr, const double *__restrict__ psi, 
 // convergence state. mode 0: after a sweep; mode 1: field initialisation (no sweep bookkeeping);
 // mode 2: exact field refresh (no relaxation, no bookkeeping).
 // ------------------------------------------------------------------------------------------------
+// fold of rows [lo, hi) of a [.][Q + 1] record table (Q sums, then a sticky-NaN max) by the workgroup, in a fixed order;
+// lane 0 leaves the result in out[0..Q] (LDS), visible to all after the closing barrier
+template <int Q, bool SC1>
+__device__ __forceinline__ void fold_rows(const double *rows, uint32_t lo, uint32_t hi, double *sacc /* LDS [BLOCK/64][Q+1] */, double *out) {
+    const int tid = threadIdx.x;
+    double acc[Q], mx = 0.0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = 0.0;
+    for (uint32_t r = lo + tid; r < hi; r += BLOCK) {
+        const double *rec = rows + size_t(r) * (Q + 1);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[q] += SC1 ? __hip_atomic_load(rec + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : rec[q];
+        mx = nanmax(mx, SC1 ? __hip_atomic_load(rec + Q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : rec[Q]);
+    }
+    block_reduce_store<Q, BLOCK / 64>(acc, mx, sacc, out);
+    __syncthreads();
+}
+template <int Q>
 __global__ void __launch_bounds__(BLOCK)
-k_finalize(const double *__restrict__ partials, uint32_t n_part, int Q, int mode, dev_params *__restrict__ P,
+k_finalize(const double *__restrict__ partials, uint32_t n_part, int mode, dev_params *__restrict__ P,
            double *__restrict__ diff_hist, uint32_t hist_cap, int md_exact /* the sweep reported 1-step differences by nature */) {
     if (mode == 0 && P->stop) return;
-    __shared__ double sacc[BLOCK * (QMAX + 1)];
+    __shared__ double sacc[(BLOCK / 64) * (Q + 1)];
+    __shared__ double sout[Q + 1];
+    fold_rows<Q, false>(partials, 0, n_part, sacc, sout);
+    if (threadIdx.x == 0) finalize_update<Q>(P, sout, mode, diff_hist, hist_cap, md_exact);
+}
+
+// K2 with its fold in ONE launch (single engine, after a sweep): workgroup b folds the contiguous chunk b of the sweep's
+// records into stage row b; the workgroup that arrives LAST at the counter folds the stage rows and runs the update. Who
+// that is depends on timing, what it reads and in which order does not, so the result is bitwise reproducible. Two
+// launches per sweep (k_fold_stage, k_finalize) were 5 + 6 us on C2 and 11 + 21 us on C4 plus a launch gap, next to sweep
+// kernels of 50 and 450 us. (The same fold inside the SWEEP launch was tried and dropped: the record must have left
+// the CU before the counter moves, so every sweep workgroup drained its message stores and waited for an atomic's return
+// before it could retire: C3 2.49 -> 2.57 ms, C2 50 -> 73 us.)
+// Visibility between the workgroups follows MI355X_MICROARCH.md (sc1 hand-off with one unsharded counter): stage rows
+// stored sc1 by one lane, that lane's s_waitcnt vmcnt(0), then its agent-scope atomic add; the workgroup whose add came
+// last reads the rows with sc1 loads behind a workgroup barrier.
+template <int Q>
+__global__ void __launch_bounds__(BLOCK)
+k_fold_finalize(const double *__restrict__ partials, uint32_t n_part, uint32_t chunk, dev_params *__restrict__ P,
+                double *__restrict__ diff_hist, uint32_t hist_cap, int md_exact, double *__restrict__ stage /* [gridDim.x][Q + 1] */,
+                uint32_t *__restrict__ counter /* zero between launches */) {
+    if (P->stop) return;
+    __shared__ double sacc[(BLOCK / 64) * (Q + 1)];
+    __shared__ double sout[Q + 1];
+    __shared__ int s_last;
     const int tid = threadIdx.x;
-    double acc[QMAX + 1];
-    for (int q = 0; q <= Q; ++q) acc[q] = 0.0;
-    for (uint32_t b = tid; b < n_part; b += BLOCK) {
-        for (int q = 0; q < Q; ++q) acc[q] += partials[size_t(b) * (Q + 1) + q];
-        acc[Q] = nanmax(acc[Q], partials[size_t(b) * (Q + 1) + Q]);
-    }
-    for (int q = 0; q <= Q; ++q) sacc[tid * (QMAX + 1) + q] = acc[q];
-    __syncthreads();
-    for (int s = BLOCK / 2; s > 0; s >>= 1) {
-        if (tid < s) {
-            for (int q = 0; q < Q; ++q) sacc[tid * (QMAX + 1) + q] += sacc[(tid + s) * (QMAX + 1) + q];
-            sacc[tid * (QMAX + 1) + Q] = nanmax(sacc[tid * (QMAX + 1) + Q], sacc[(tid + s) * (QMAX + 1) + Q]);
+    const uint32_t lo = blockIdx.x * chunk, hi = min(n_part, lo + chunk);
+    fold_rows<Q, false>(partials, lo, hi, sacc, sout);
+    if (gridDim.x > 1) {
+        if (tid == 0) {
+#pragma unroll
+            for (int q = 0; q <= Q; ++q) __hip_atomic_store(stage + size_t(blockIdx.x) * (Q + 1) + q, sout[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row has left this CU before the counter moves
+            s_last = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1 : 0;
         }
         __syncthreads();
+        if (!s_last) return;  // uniform
+        fold_rows<Q, true>(stage, 0, gridDim.x, sacc, sout);
+        if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     }
-    if (tid == 0) {
-        double S[QMAX];
-        const double mix = P->field_mix;
-        for (int q = 0; q < Q; ++q) {
-            double s = sacc[q];
-            if (mode == 0 && P->have_prev && mix < 1.0) s = (1.0 - mix) * P->S[q] + mix * s;
-            S[q] = s;
-            P->S[q] = s;
-        }
-        P->have_prev = 1;
-        for (int q1 = 0; q1 < Q; ++q1) {  // h[q1] = sum_q2 cab[q2][q1] S[q2]   (bp.cpp:341-355)
-            double h = 0.0;
-            for (int q2 = 0; q2 < Q; ++q2) h += P->cab[q2 * Q + q1] * S[q2];
-            const double hN = h * P->invN;
-            P->hN[q1] = hN;
-            P->etaF[q1] = P->eta[q1] * exp(-P->beta * hN);
-        }
-        if (mode == 0) {
-            const double md = sacc[Q];
-            P->maxdiff = md;
-            const int it = P->sweep_idx;
-            if (diff_hist != nullptr && uint32_t(it) < hist_cap) diff_hist[it] = md;
-            const bool is_hint = P->hinted && !P->exact && !md_exact;
-            P->last_exact = is_hint ? 0 : 1;
-            if (is_hint) {  // a 2-step hint: it can only arm the exact criterion
-                double scale = HINT_SCALE;
-                if (P->prev_hint > 0.0 && md > 0.0 && md < P->prev_hint) {
-                    const double r = md / P->prev_hint;
-                    scale = fmin(HINT_SCALE_MAX, fmax(HINT_SCALE, 1.5 * (1.0 + 1.0 / r) / r));
-                }
-                P->prev_hint = md;
-                if (md < scale * P->crit) P->exact = 1;
-            } else if (md < P->crit && P->conv_iter < 0) {
-                P->conv_iter = it;
-                P->stop = 1;
-            }
-            P->sweep_idx = it + 1;
-        }
-    }
+    if (tid == 0) finalize_update<Q>(P, sout, 0, diff_hist, hist_cap, md_exact);
 }
 
 // ------------------------------------------------------------------------------------------------
