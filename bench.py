@@ -42,6 +42,7 @@ WORKLOADS = {
     # the same Q and mean degree as C4 on a plain planted partition (Poisson degrees): separates what Q = 8 costs from what the
     # power-law degrees cost
     "Q8": (1_000_000, 8, 8.0, 0.1, 0, 3),
+    "Q8dc": (1_000_000, 8, 8.0, 0.1, 1, 3),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 CONV_CRIT = 5e-6       # the reference's default -e (main.cpp:113)
@@ -236,6 +237,8 @@ def main():
         else:
             pairs, cin, cout = synth.planted_partition(N, Q, c, eps, gseed)
             cab_mat = synth.cab_matrix(Q, cin, cout)
+            if dc == 1:  # control workloads: Poisson degrees under the degree-corrected model (cab scaled as dc_sbm_powerlaw does)
+                cab_mat = cab_mat / (2.0 * len(pairs) / N) ** 2
         g = S.Graph.from_edges(pairs, N)
         del pairs
         bm = S.blockmodel_t(g, Q, dc)
@@ -302,7 +305,10 @@ def main():
     st = runner.stats()
     phases = runner.phase_times() if sharded else None
     kernel_ms = st.sweep_kernel_ms / max(1, st.sweep_launches)
-    bytes_per_launch = st.bytes_per_sweep  # this rank's rows/edges: what ONE launch of k_sweep processes
+    # what ONE launch of the timed kernel processes: this rank's rows and edges, minus the hub rows (above one segment's
+    # edge capacity), which the fragment kernels update in launches of their own (C4: 8 % of the edges)
+    hub_edges = int(getattr(st, "hub_edges", 0))
+    bytes_per_launch = st.bytes_per_sweep - hub_edges * (24.0 * Q + 4.0) - int(st.n_hub_rows) * (8.0 * Q + 8.0)
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
 
     converge = None
@@ -333,7 +339,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: planted SBM N=%d Q=%d c=%g eps=%g deg_corr=%d, synchronous BP sweep (-m infer inner loop)" % (
-                args.workload, N, Q, c, eps, dc), "N": N, "Q": Q, "E2": int(E2_total), "hub_rows": int(st.n_hub_rows), "parallelism": "vertex-range shards x%d%s" % (world, " (sharded driver)" if sharded else ""),
+                args.workload, N, Q, c, eps, dc), "N": N, "Q": Q, "E2": int(E2_total), "hub_rows": int(st.n_hub_rows), "hub_edges": hub_edges, "parallelism": "vertex-range shards x%d%s" % (world, " (sharded driver)" if sharded else ""),
                 "setup_s": round(setup_s, 2)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -186,8 +186,9 @@ typedef struct sbmbp_stats {
     double bytes_per_sweep;      /* algorithmic bytes of one sweep */
     uint64_t device_bytes;       /* HBM held by this engine */
     uint32_t n_blocks;           /* workgroups of one sweep launch */
-    uint32_t n_hub_rows;         /* rows handled by the workgroup-per-row kernel */
+    uint32_t n_hub_rows;         /* rows above one segment's edge capacity: updated by the hub kernels, not by the frame kernel */
     uint64_t psi_form_sweeps;    /* of `sweeps`, how many ran the marginal-gather form */
+    uint64_t hub_edges;          /* directed edges of those rows (sweep_kernel_ms times the frame kernel: it moves the other edges) */
 } sbmbp_stats;
 int sbmbp_get_stats(sbmbp_engine_t *e, sbmbp_stats *out);
 int sbmbp_reset_stats(sbmbp_engine_t *e);

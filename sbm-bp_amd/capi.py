@@ -30,7 +30,8 @@ class LearnResult(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("sweeps", C.c_uint64), ("edge_msg_updates", C.c_uint64), ("sweep_kernel_ms", C.c_double),
                 ("sweep_launches", C.c_uint64), ("bytes_per_sweep", C.c_double), ("device_bytes", C.c_uint64),
-                ("n_blocks", C.c_uint32), ("n_hub_rows", C.c_uint32), ("psi_form_sweeps", C.c_uint64)]
+                ("n_blocks", C.c_uint32), ("n_hub_rows", C.c_uint32), ("psi_form_sweeps", C.c_uint64),
+                ("hub_edges", C.c_uint64)]
 
 
 class DistInfo(C.Structure):

@@ -63,6 +63,7 @@ struct sbmbp_engine {
     double *d_hub_b = nullptr, *d_hub_pA = nullptr;
     int *d_hub_pE = nullptr;
     uint32_t n_frag = 0;
+    uint64_t hub_edges = 0;
     std::vector<uint32_t> h_hub_frag0;  // [n_hub + 1]
     uint32_t *d_fold_counters = nullptr;  // arrival counter of k_fold_finalize (zero between launches)
     int32_t *d_clamp = nullptr;
@@ -230,6 +231,7 @@ int setup_hub_frags(sbmbp_engine *e, const std::vector<uint32_t> &hub_row, const
     e->h_hub_frag0.assign(1, 0u);
     for (size_t h = 0; h < hub_row.size(); ++h) {
         const uint32_t d = rp32[hub_row[h] + 1] - rp32[hub_row[h]];
+        e->hub_edges += d;
         for (uint32_t k = 0; k < (d + BLOCK - 1) / BLOCK; ++k) frag_hub.push_back(uint32_t(h));
         e->h_hub_frag0.push_back(uint32_t(frag_hub.size()));
     }
@@ -1403,6 +1405,7 @@ int sbmbp_get_stats(sbmbp_engine_t *e, sbmbp_stats *out) {
     out->device_bytes = e->device_bytes;
     out->n_blocks = e->n_blk;
     out->n_hub_rows = e->n_hub;
+    out->hub_edges = e->hub_edges;
     out->psi_form_sweeps = e->psi_sweeps;
     return SBMBP_OK;
 }

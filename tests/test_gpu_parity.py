@@ -404,6 +404,68 @@ def test_marginal_gather_and_message_gather_forms_agree(S):
     assert np.abs(a0[5] - a1[5]).max() < 1e-11 and abs(a0[6] - a1[6]) < 1e-11
 
 
+def test_extreme_hub_row_in_fragments(S, orc):
+    """one vertex joined to 20 000 others (79 fragments of 256 edges for the marginal-gather sweep) on top of a sparse planted
+    partition: sweeps, marginals, messages and the free energy against the oracle, with and without degree correction, both
+    sweep forms, and with the hub clamped (its fragments copy the marginal and leave the messages alone)"""
+    from sbm_bp_amd import synth
+    N, Q = 30000, 3
+    pairs, cin, cout = synth.planted_partition(N, Q, 4.0, 0.2, 11)
+    rng = np.random.default_rng(5)
+    hub = 12345
+    others = rng.choice(np.delete(np.arange(N), hub), size=20000, replace=False).astype(np.uint32)
+    star = np.stack([np.minimum(others, hub), np.maximum(others, hub)], axis=1).astype(np.uint32)
+    key = np.unique(np.concatenate([pairs[:, 0].astype(np.int64) * N + pairs[:, 1], star[:, 0].astype(np.int64) * N + star[:, 1]]))
+    pairs = np.stack([key // N, key % N], axis=1).astype(np.uint32)
+    g = S.Graph.from_edges(pairs, N)
+    og = orc.Graph.from_edges(pairs, N)
+    assert g.max_degree >= 20000
+    tc = synth.true_conf(N, Q)
+    na = np.array(synth.group_sizes(N, Q), dtype=np.uint32)
+    c_eff = 2.0 * len(pairs) / N
+    for dc, cab in ((0, synth.cab_matrix(Q, cin, cout)), (1, synth.cab_matrix(Q, cin, cout) / (c_eff * c_eff))):
+        obp = orc.OracleBP(og, Q, dc)
+        obp.init_messages(0, None, tc, orc.Rng(3))
+        obp.set_params(cab, na, 1.0)
+        od = [obp.sweep_sync(1.0) for _ in range(5)]
+        opsi, omsg = obp.get_state()
+        obp.compute_h()  # the field of the CURRENT marginals, as the engine (and the reference's incremental h) evaluates f_site with
+        ofe, _ = obp.free_energy(0)
+        for mode in (0, 1):
+            bp = S.bp_conditional()
+            bp.init_messages(S.blockmodel_t(g, Q, dc), 0, None, tc, 3)
+            bp.expand_bp_params(S.bp_blockmodel_state(cab, na))
+            bp.set_gather_mode(mode)
+            assert bp.stats().n_hub_rows == 1 and bp.stats().hub_edges >= 20000
+            d = [bp.sweep(1, 1.0) for _ in range(5)]
+            psi, msg = bp.get_state()
+            assert np.abs(np.array(d) - np.array(od)).max() < 1e-9, (dc, mode, d, od)
+            assert np.abs(psi - opsi).max() < 1e-9 and np.abs(msg - omsg).max() < 1e-9, (dc, mode)
+            assert abs(bp.compute_free_energy() - ofe) < 1e-9 * max(1.0, abs(ofe)), (dc, mode)
+            assert (bp.stats().psi_form_sweeps > 0) == (mode == 0)
+    # the hub clamped (-i 1 style beliefs): marginal-gather form only runs without clamps on the hub's NEIGHBOURS being special,
+    # so compare the engine's own two forms and the oracle
+    beliefs = np.full(N, -1, dtype=np.int32)
+    beliefs[hub] = 1
+    beliefs[7] = 0
+    cab = synth.cab_matrix(Q, cin, cout)
+    obp = orc.OracleBP(og, Q, 0)
+    obp.init_messages(1, beliefs, tc, orc.Rng(3))
+    obp.set_params(cab, na, 1.0)
+    od = [obp.sweep_sync(1.0) for _ in range(4)]
+    opsi, omsg = obp.get_state()
+    for mode in (0, 1):
+        bp = S.bp_conditional()
+        bp.init_messages(S.blockmodel_t(g, Q, 0), 1, beliefs, tc, 3)
+        bp.expand_bp_params(S.bp_blockmodel_state(cab, na))
+        bp.set_gather_mode(mode)
+        d = [bp.sweep(1, 1.0) for _ in range(4)]
+        psi, msg = bp.get_state()
+        assert np.abs(np.array(d) - np.array(od)).max() < 1e-9, (mode, d, od)
+        assert np.abs(psi - opsi).max() < 1e-9 and np.abs(msg - omsg).max() < 1e-9, mode
+        assert psi[hub, 1] == 1.0 and psi[7, 0] == 1.0
+
+
 def test_degree_corrected_powerlaw_graph_c4_family(S, orc):
     """config C4 family at test size: DC-SBM with power-law propensities, Q=8, --deg_corr_flag 1; rows
     above the segment capacity go through the hub kernels, everything is checked against the oracle"""
