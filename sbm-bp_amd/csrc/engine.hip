@@ -1827,7 +1827,7 @@ int sbmbp_shard_sweep_fold(sbmbp_engine_t *e) {
     IS_SHARD(e);
     const uint32_t rows = e->n_blk;
     const uint32_t chunk = std::max<uint32_t>(1, (rows + SBMBP_FOLD_ROWS - 1) / SBMBP_FOLD_ROWS);
-    hipLaunchKernelGGL(k_fold_stage, dim3(SBMBP_FOLD_ROWS), dim3(BLOCK), 0, e->stream, e->d_partials, rows, chunk, int(e->Q), 1, e->Q + 1, e->d_red);
+    DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fold_records<QQ>), dim3(SBMBP_FOLD_ROWS), dim3(BLOCK), 0, e->stream, e->d_partials, rows, chunk, e->d_red));
     HIPCHK(hipGetLastError());
     return SBMBP_OK;
 }

@@ -1437,6 +1437,19 @@ k_finalize(const double *__restrict__ partials, uint32_t n_part, int mode, dev_p
 // Visibility between the workgroups follows MI355X_MICROARCH.md (sc1 hand-off with one unsharded counter): stage rows
 // stored sc1 by one lane, that lane's s_waitcnt vmcnt(0), then its agent-scope atomic add; the workgroup whose add came
 // last reads the rows with sc1 loads behind a workgroup barrier.
+// workgroup b folds the contiguous chunk b of a [rows][Q + 1] record table into out row b (the per-sweep fold of a shard:
+// SBMBP_FOLD_ROWS rows per rank go into the all-gather). Compile-time Q: the generic k_fold_stage walks the columns one by
+// one with a barrier tree each, 12 us where this takes 4.
+template <int Q>
+__global__ void __launch_bounds__(BLOCK)
+k_fold_records(const double *__restrict__ partials, uint32_t rows, uint32_t chunk, double *__restrict__ out) {
+    __shared__ double sacc[(BLOCK / 64) * (Q + 1)];
+    __shared__ double sout[Q + 1];
+    const uint32_t lo = min(rows, blockIdx.x * chunk), hi = min(rows, lo + chunk);
+    fold_rows<Q, false>(partials, lo, hi, sacc, sout);
+    if (threadIdx.x <= Q) out[size_t(blockIdx.x) * (Q + 1) + threadIdx.x] = sout[threadIdx.x];
+}
+
 template <int Q>
 __global__ void __launch_bounds__(BLOCK)
 k_fold_finalize(const double *__restrict__ partials, uint32_t n_part, uint32_t chunk, dev_params *__restrict__ P,

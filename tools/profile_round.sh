@@ -7,6 +7,13 @@ R=${1:-r02}
 OUT=gpurun_out/profile_$R
 mkdir -p $OUT
 export TMPDIR=/tmp
+python3 -c "from bench import source_sha; print(source_sha())" > $OUT/source_sha.txt  # the sources everything below is measured on
+# counters first: the benches below then find a PMC summary collected on THESE sources and report roofline.traffic from it
+for CTR in FETCH_SIZE WRITE_SIZE TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum; do
+  echo "== pmc $CTR" >&2
+  rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d $OUT/pmc_$CTR -o run -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > $OUT/pmc_$CTR.log 2>&1 || echo "pmc $CTR failed" >&2
+done
+python3 tools/summarise_profiles.py $R pmc
 for WL in C3 C2 C4 C5; do
   echo "== bench $WL" >&2
   if [ $WL = C3 ]; then python3 bench.py --workload $WL --converge > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err || exit 1
@@ -17,10 +24,6 @@ for WL in C3 C2 C4 C5; do
 done
 echo "== bench C3 --gather messages" >&2
 python3 bench.py --workload C3 --no-cpu-baseline --gather messages > $OUT/bench_C3_messages.json 2> $OUT/bench_C3_messages.err || exit 1
-for CTR in FETCH_SIZE WRITE_SIZE TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum; do
-  echo "== pmc $CTR" >&2
-  rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d $OUT/pmc_$CTR -o run -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > $OUT/pmc_$CTR.log 2>&1 || echo "pmc $CTR failed" >&2
-done
 echo "== per-rank budget of the 8-rank C3 plan" >&2
 for CH in 1 2 4; do
   SBMBP_SHARD_CHUNKS=$CH python3 tools/shard_budget.py C3 8 0 20 $OUT/budget_c3_w8_c$CH.json 2>/dev/null | tail -1 >&2
