@@ -832,7 +832,9 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     __shared__ double sred[frame_cfg<Q>::WAVES * (Q + 1)];
     __shared__ int sbig;  // the segment holds a row above BIG_ROW edges
     __shared__ uint8_t sfl[CLAMP ? RCAP : 1];  // 1 = clamped row
-    constexpr int SLOTS = SHARD ? 4 * RCAP : 1;          // send slots of the segment's rows kept in LDS (the rest from HBM)
+    // send slots of the segment's rows kept in LDS (the rest from HBM): 2 * RCAP keeps the Q = 4 workgroup under 32 KB of LDS
+    // (5 per CU; 4 * RCAP was 34 KB = 4 per CU); the 8-rank C3 plan has ~150 slots per segment. Measured neutral there.
+    constexpr int SLOTS = SHARD ? 2 * RCAP : 1;
     __shared__ uint32_t ssp[SHARD ? RCAP + 1 : 1];       // send-slot offsets of the rows, relative to the segment
     __shared__ uint32_t sslot[SLOTS];
     __shared__ uint16_t ssrow[SLOTS];                    // row (within the segment) of every send slot
