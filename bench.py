@@ -273,7 +273,39 @@ def main():
                 # buffers staged through the host (the line names the transport; it is not the design's data path)
                 comm = Comm.callbacks_from_torch(group=dist.new_group(backend="gloo"))
                 comm_note = comm_note or "RCCL communicator creation failed on another rank"
-        runner = ShardedBP.synthetic(N, Q, c, eps, gseed, dc=dc, seed=1234, comm=comm, device=local_rank)
+        # The number of row chunks per sweep trades kernel efficiency (fewer, larger launches) against how much of the halo
+        # exchange hides behind the next chunk's sweep, and which side wins depends on the links of THIS node: measure it.
+        # Every rank builds the same candidates in the same order, times a few sweeps between barriers, and the maximum over
+        # the ranks decides for all of them (untimed set-up; SBMBP_SHARD_CHUNKS=k pins the count instead).
+        chunk_trials = None
+        if world > 1 and not os.environ.get("SBMBP_SHARD_CHUNKS"):
+            chunk_trials, runner, graph = {}, None, None
+            for nc in (1, 2, 4, 8):
+                cand = ShardedBP.synthetic(N, Q, c, eps, gseed, dc=dc, seed=1234, comm=comm, device=local_rank, n_chunks=nc, graph=graph)
+                graph = cand.graph
+                cand.sweep(2, 1.0, want_diff=False)
+                best_try = None
+                for _ in range(2):  # the better of two blocks of five sweeps (max over the ranks each)
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    t_try = time.perf_counter()
+                    cand.sweep(5, 1.0, want_diff=False)
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    t_loc = torch.tensor([time.perf_counter() - t_try], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+                    dist.all_reduce(t_loc, op=dist.ReduceOp.MAX)
+                    best_try = float(t_loc.item()) if best_try is None else min(best_try, float(t_loc.item()))
+                chunk_trials[nc] = best_try / 5 * 1e3
+                if runner is None or chunk_trials[nc] < 0.98 * chunk_trials[best_nc]:
+                    if runner is not None:
+                        runner.close()
+                    runner, best_nc = cand, nc
+                else:
+                    cand.close()
+            runner.init_messages_device(1234, tc)
+            runner.expand_bp_params(runner.cab, runner.na, 1.0)
+        else:
+            runner = ShardedBP.synthetic(N, Q, c, eps, gseed, dc=dc, seed=1234, comm=comm, device=local_rank)
         E2_total = runner.E2_global
 
         def reinit():
@@ -358,6 +390,8 @@ def main():
             per_peer = runner.peer_rows()[0].astype(float) * info.halo_components * 8 / 1e6
             if comm_note:
                 out["config"]["comm_fallback"] = comm_note
+            if chunk_trials:
+                out["config"]["chunk_trials_ms_per_sweep"] = {str(k): round(v, 4) for k, v in chunk_trials.items()}
             out["config"]["exchange"] = {"transport": runner.comm.transport, "chunks": int(info.n_chunks),
                                          "payload_components": int(info.halo_components), "halo_rows": int(info.n_halo),
                                          "sent_MB_per_sweep": round(float(per_peer.sum()), 2),

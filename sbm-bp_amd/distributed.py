@@ -146,14 +146,19 @@ class ShardedBP:
 
     # -- construction -------------------------------------------------------------------------
     @classmethod
-    def synthetic(cls, N, Q, c, eps, graph_seed, dc=0, seed=1234, comm=None, device=0):
-        """every rank generates the same planted-partition graph and keeps its own row range"""
+    def synthetic(cls, N, Q, c, eps, graph_seed, dc=0, seed=1234, comm=None, device=0, n_chunks=0, graph=None):
+        """every rank generates the same planted-partition graph and keeps its own row range (graph: the host graph of an
+        earlier call with the same arguments, kept in .graph, to build another plan on it)"""
         import sbm_bp_amd as S
         from sbm_bp_amd import synth
-        pairs, cin, cout = synth.planted_partition(N, Q, c, eps, graph_seed)
-        g = S.Graph.from_edges(pairs, N)
-        del pairs
-        self = cls(g, Q, dc, comm, device)
+        cin, cout = synth.cin_cout(Q, c, eps)
+        g = graph
+        if g is None:
+            pairs, cin, cout = synth.planted_partition(N, Q, c, eps, graph_seed)
+            g = S.Graph.from_edges(pairs, N)
+            del pairs
+        self = cls(g, Q, dc, comm, device, n_chunks)
+        self.graph = g
         self.init_messages_device(seed, synth.true_conf(N, Q))
         self.expand_bp_params(synth.cab_matrix(Q, cin, cout), np.array(synth.group_sizes(N, Q), dtype=np.uint32), 1.0)
         return self
