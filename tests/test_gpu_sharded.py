@@ -285,6 +285,22 @@ def test_rccl_transport_with_one_rank(S, orc):
     res = sb.inference(1e-12, 3000, 1.0)
     assert res["niter"] >= 0 and abs(res["free_energy"] - r["f"]) < 2e-9 * max(1.0, abs(r["f"]))
     sb.close()
+    # several drivers one after the other on the SAME communicators, with different chunk counts: what bench.py --gpus N does
+    # when it measures the chunk count (one plan per candidate, the losers closed)
+    first = None
+    for nc in (1, 4, 2):
+        sb = ShardedBP(S.Graph.from_csr(g.row_ptr, g.nbr), a["Q"], 0, comm, 0, nc)
+        assert sb.info.n_chunks == nc
+        sb.init_messages_device(7, a["true_conf"])
+        sb.set_state(psi0, msg0)
+        sb.expand_bp_params(cab, na, 1.0)
+        d = sb.sweep(4, 1.0)
+        psi, _ = sb.get_state()
+        if first is None:
+            first = (d, psi)
+        else:
+            assert abs(d - first[0]) < 1e-14 and np.abs(psi - first[1]).max() < 1e-14
+        sb.close()
 
 
 @pytest.mark.parametrize("name,world", [("q4_tight_seed0", 3)])
