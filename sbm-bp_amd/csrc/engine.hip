@@ -68,8 +68,6 @@ struct sbmbp_engine {
     uint32_t *d_fold_counters = nullptr;  // arrival counter of k_fold_finalize (zero between launches)
     int32_t *d_clamp = nullptr;
     uint32_t n_blk = 0, n_hub = 0;
-    hipStream_t hub_stream = nullptr;  // hub rows (one workgroup each, latency-bound) run beside the frame kernel
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // state in HBM
     double *d_M[2] = {nullptr, nullptr};
     int cur = 0;
@@ -261,6 +259,25 @@ int launch_hub_psi(sbmbp_engine *e, hipStream_t st, uint32_t h0, uint32_t nh, do
     return SBMBP_OK;
 }
 
+// message-gather update of all hub rows: the same two launches over their fragments, incoming messages gathered through rev
+int launch_hub_msg(sbmbp_engine *e, hipStream_t st, const double *Mold, double *Mnew, const double *psi_old, double *psi_new,
+                   const int32_t *clamp, double damp) {
+    if (!e->n_hub) return SBMBP_OK;
+    const uint32_t nf = e->n_frag;
+    const hub_frags hf{e->d_frag_hub, e->d_hub_frag0, e->d_hub_b, e->d_hub_pA, e->d_hub_pE};
+    if (e->dc == 2) {
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_hub_frag_product_msg<QQ, true>), dim3(nf), dim3(BLOCK), 0, st, e->d_row_ptr, e->d_rev, e->d_nbr,
+                                            e->d_deg, Mold, e->d_hub_row, e->d_hub_blk, hf, 0u, e->d_P, e->d_partials, clamp));
+    } else {
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_hub_frag_product_msg<QQ, false>), dim3(nf), dim3(BLOCK), 0, st, e->d_row_ptr, e->d_rev, e->d_nbr,
+                                            e->d_deg, Mold, e->d_hub_row, e->d_hub_blk, hf, 0u, e->d_P, e->d_partials, clamp));
+    }
+    DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_hub_frag_cavity_msg<QQ>), dim3(nf), dim3(BLOCK), 0, st, e->d_row_ptr, Mold, Mnew, psi_old, psi_new,
+                                        e->d_hub_row, e->d_hub_blk, hf, 0u, e->d_P, int(e->dc != 0), damp,
+                                        e->d_partials, clamp));
+    return SBMBP_OK;
+}
+
 // h from the current psi (init_h, bp.cpp:320-332); mode 1 = converge start, 2 = exact refresh
 int launch_field(sbmbp_engine *e, int mode) {
     const uint32_t rows_per_blk = 4096;
@@ -286,35 +303,11 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form, bool f
     const int32_t *clamp = e->has_clamp ? e->d_clamp : nullptr;
     // hub rows first, on their own stream: a few hundred long-running workgroups that overlap with the frame kernel
     // (disjoint rows and edges; both only read psi_old and the parameter block)
-    // Hub rows. Marginal-gather form: fragment kernels on the sweep's own stream (they are throughput-bound like the frame
-    // kernel: beside it on a second stream they gained nothing, C4 0.545 vs 0.533 ms per sweep). Message-gather form: one
-    // workgroup per hub row, latency-bound, on their own stream beside the frame kernel.
-    const bool hub_serial = psi_form;
+    // Hub rows first, in fragments, on the sweep's own stream (disjoint rows and edges from the frame kernel's; they are
+    // throughput-bound like it: beside it on a second stream they gained nothing, C4 0.545 vs 0.533 ms per sweep).
     if (e->n_hub) {
-        if (!hub_serial && !e->hub_stream) {
-            HIPCHK(hipStreamCreateWithFlags(&e->hub_stream, hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
-        }
-        hipStream_t hs = hub_serial ? e->stream : e->hub_stream;
-        if (!hub_serial) {
-            HIPCHK(hipEventRecord(e->ev_fork, e->stream));
-            HIPCHK(hipStreamWaitEvent(hs, e->ev_fork, 0));
-        }
-        if (psi_form) {
-            CHK(launch_hub_psi(e, hs, 0, e->n_hub, Mnew, psi_old, psi_new, clamp, shard_io{}, Mold, int(first_from_psi)));
-        } else {
-            if (e->dc == 2) {
-                DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, hs,
-                                                    e->d_row_ptr, e->d_rev, e->d_nbr, e->d_deg, Mold, Mnew, psi_old, psi_new, clamp,
-                                                    e->d_hub_row, e->d_hub_blk, e->d_P, 1, damp, e->d_partials));
-            } else {
-                DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, false>), dim3(e->n_hub), dim3(BLOCK), 0, hs,
-                                                    e->d_row_ptr, e->d_rev, e->d_nbr, e->d_deg, Mold, Mnew, psi_old, psi_new, clamp,
-                                                    e->d_hub_row, e->d_hub_blk, e->d_P, int(e->dc), damp, e->d_partials));
-            }
-        }
-        if (!hub_serial) HIPCHK(hipEventRecord(e->ev_join, hs));
+        if (psi_form) CHK(launch_hub_psi(e, e->stream, 0, e->n_hub, Mnew, psi_old, psi_new, clamp, shard_io{}, Mold, int(first_from_psi)));
+        else CHK(launch_hub_msg(e, e->stream, Mold, Mnew, psi_old, psi_new, clamp, damp));
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (e->timing) {
@@ -348,7 +341,6 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form, bool f
                                             int(e->dc), damp, e->d_partials));
     }
     if (e->timing) HIPCHK(hipEventRecord(e1, e->stream));
-    if (e->n_hub && !hub_serial) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
     // fold of the segment records + K2 in one launch (k_fold_finalize): <= FOLD_BLOCKS workgroups of >= 2048 records each
     if (!e->d_fold_counters) {
         CHK(dev_alloc(e, &e->d_fold_counters, 1));
@@ -1013,9 +1005,6 @@ void sbmbp_destroy(sbmbp_engine_t *e) {
     for (auto ev : e->ev) hipEventDestroy(ev);
     if (e->h_cs) (void)hipHostFree(e->h_cs);
     for (auto ev : e->ev_cs) if (ev) hipEventDestroy(ev);
-    if (e->ev_fork) hipEventDestroy(e->ev_fork);
-    if (e->ev_join) hipEventDestroy(e->ev_join);
-    if (e->hub_stream) hipStreamDestroy(e->hub_stream);
     if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1650,15 +1639,7 @@ int sbmbp_shard_sweep_explicit(sbmbp_engine_t *e, uint32_t j, double damping) {
         }
     }
     if (e0) HIPCHK(hipEventRecord(e1, e->stream));
-    if (e->n_hub) {
-        if (e->dc == 2) {
-            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_rev, e->d_nbr,
-                                                e->d_deg, Mold, Mnew, psi_old, psi_new, clamp, e->d_hub_row, e->d_hub_blk, e->d_P, 1, damping, e->d_partials));
-        } else {
-            DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_sweep_hub<QQ, false>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_rev, e->d_nbr,
-                                                e->d_deg, Mold, Mnew, psi_old, psi_new, clamp, e->d_hub_row, e->d_hub_blk, e->d_P, int(e->dc), damping, e->d_partials));
-        }
-    }
+    CHK(launch_hub_msg(e, e->stream, Mold, Mnew, psi_old, psi_new, clamp, damping));
     HIPCHK(hipGetLastError());
     return SBMBP_OK;
 }

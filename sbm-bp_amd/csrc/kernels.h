@@ -545,7 +545,7 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
     const uint32_t r0 = blk_row[blockIdx.x], r1 = blk_row[blockIdx.x + 1];
     const uint32_t e0 = blk_e0[blockIdx.x];
     const int nrows = int(r1 - r0), ne = int(blk_e0[blockIdx.x + 1] - e0);
-    if (stop || ne > CAP) return;  // stopped run, or hub row (k_sweep_hub owns it): uniform exit before any barrier
+    if (stop || ne > CAP) return;  // stopped run, or hub row (the fragment kernels own it): uniform exit before any barrier
 
     // ---- phase 1: lane per directed edge: gather incoming message, b = W^T m -> LDS (branch-free loads,
     // see k_sweep_psi)
@@ -1289,87 +1289,120 @@ k_msg_diff(const double *__restrict__ a, const double *__restrict__ b, uint64_t 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1h: the same update for one hub row per workgroup (degree > CAP): product with a tracked
-// common exponent, two gather passes.
+// K1h: the message-gather update of the hub rows (degree > CAP), in the same fragments of BLOCK edges as the
+// marginal-gather form (k_hub_frag_product / k_hub_frag_cavity above): the product launch gathers the incoming messages
+// through rev, the cavity launch damps and writes the other message buffer. Differences reported are 1-step differences.
 // ------------------------------------------------------------------------------------------------
 template <int Q, bool DC2>
 __global__ void __launch_bounds__(BLOCK)
-k_sweep_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr, const uint32_t *__restrict__ ndeg /* degree of every table row (DC2 only) */,
-            const double *__restrict__ Mold, double *__restrict__ Mnew, const double *__restrict__ psi_old,
-            double *__restrict__ psi, const int32_t *__restrict__ clamp, const uint32_t *__restrict__ hub_row,
-            const uint32_t *__restrict__ hub_blk, const dev_params *__restrict__ P, int dc, double damp,
-            double *__restrict__ partials) {
+k_hub_frag_product_msg(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr,
+                       const uint32_t *__restrict__ ndeg /* degree of every table row (DC2 only) */, const double *__restrict__ Mold,
+                       const uint32_t *__restrict__ hub_row, const uint32_t *__restrict__ hub_blk, hub_frags hf, uint32_t frag_first,
+                       const dev_params *__restrict__ P, double *__restrict__ partials, const int32_t *__restrict__ clamp) {
     if (P->stop) return;
-    __shared__ double sAq[BLOCK * Q];
-    __shared__ int sEq[BLOCK * Q];
-    __shared__ double sred[4 * (Q + 1)];
+    __shared__ double sAw[(BLOCK / 64) * Q];
+    __shared__ int sEw[(BLOCK / 64) * Q];
     const int tid = threadIdx.x;
-    const uint32_t i = hub_row[blockIdx.x];
+    const uint32_t f = frag_first + blockIdx.x, h = hf.frag_hub[f], k = f - hf.hub_frag0[h];
+    const uint32_t i = hub_row[h];
+    const uint32_t e0 = row_ptr[i], d = row_ptr[i + 1] - e0;
+    if (k == 0 && tid == 0) partials[size_t(hub_blk[h]) * (Q + 1) + Q] = 0.0;  // the row's difference record: the fragments max into it
+    if (clamp != nullptr && clamp[i] != -1) return;  // clamped hub (uniform)
+    const uint32_t le = k * BLOCK + tid;
+    const bool ok = le < d;
+    const uint32_t lc = ok ? le : d - 1;
+    double m[Q], b[Q];
+    load_msg<Q>(Mold, rev[e0 + lc], m);
+    double didl = 0.0;
+    if (DC2) { const uint32_t l = nbr[e0 + lc]; didl = double(d) * double(ndeg[l]); }
+    edge_field<Q, DC2>(P, m, didl, b);
+    if (ok) store_vec<Q>(hf.b + (size_t(f) * BLOCK + tid) * Q, b);
+    double A[Q];
+    int ae[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { A[q] = ok ? b[q] : 1.0; ae[q] = 0; }
+    block_product_shfl<Q, BLOCK / 64>(A, ae, sAw, sEw);
+    if (tid == 0) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { hf.pA[size_t(f) * Q + q] = A[q]; hf.pE[size_t(f) * Q + q] = ae[q]; }
+    }
+}
+template <int Q>
+__global__ void __launch_bounds__(BLOCK)
+k_hub_frag_cavity_msg(const uint32_t *__restrict__ row_ptr, const double *__restrict__ Mold, double *__restrict__ Mnew,
+                      const double *__restrict__ psi_old, double *__restrict__ psi, const uint32_t *__restrict__ hub_row,
+                      const uint32_t *__restrict__ hub_blk, hub_frags hf, uint32_t frag_first, const dev_params *__restrict__ P, int dc,
+                      double damp, double *__restrict__ partials, const int32_t *__restrict__ clamp) {
+    if (P->stop) return;
+    __shared__ double sAw[(BLOCK / 64) * Q];
+    __shared__ int sEw[(BLOCK / 64) * Q];
+    __shared__ double smd[BLOCK / 64];
+    const int tid = threadIdx.x;
+    const uint32_t f = frag_first + blockIdx.x, h = hf.frag_hub[f], f0 = hf.hub_frag0[h], nf = hf.hub_frag0[h + 1] - f0;
+    const uint32_t i = hub_row[h];
     const uint32_t e0 = row_ptr[i], d = row_ptr[i + 1] - e0;
     const double di = double(d);
-    const bool clamped = (clamp != nullptr && clamp[i] != -1);
-    double Sacc[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) Sacc[q] = 0.0;
-    double md = 0.0;
-    if (clamped) {
-        for (uint32_t le = tid; le < d; le += BLOCK) {
+    const uint32_t le = (f - f0) * BLOCK + tid;
+    double *rec = partials + size_t(hub_blk[h]) * (Q + 1);
+    if (clamp != nullptr && clamp[i] != -1) {  // clamped hub (uniform): marginal and out-messages stay as initialised (bp.cpp:1115-1124)
+        if (le < d) {
             double m[Q];
             load_msg<Q>(Mold, size_t(e0 + le), m);
             store_msg<Q>(Mnew, size_t(e0 + le), m);
         }
-        if (tid == 0) {
+        if (f == f0 && tid == 0) {
             double pv[Q];
             load_vec<Q>(psi_old + size_t(i) * Q, pv);
             store_vec<Q>(psi + size_t(i) * Q, pv);
 #pragma unroll
-            for (int q = 0; q < Q; ++q) Sacc[q] = (dc ? di : 1.0) * pv[q];
+            for (int q = 0; q < Q; ++q) rec[q] = (dc ? di : 1.0) * pv[q];
         }
-    } else {
-        double A[Q];
-        int ae[Q];
-#pragma unroll
-        for (int q = 0; q < Q; ++q) { A[q] = 1.0; ae[q] = 0; }
-        for (uint32_t le = tid; le < d; le += BLOCK) {
-            double m[Q], b[Q];
-            load_msg<Q>(Mold, rev[e0 + le], m);
-            double didl = 0.0;
-            if (DC2) { const uint32_t l = nbr[e0 + le]; didl = di * double(ndeg[l]); }
-            edge_field<Q, DC2>(P, m, didl, b);
-#pragma unroll
-            for (int q = 0; q < Q; ++q) A[q] *= b[q];
-            x_norm<Q>(A, ae);
-        }
-        block_product_x<Q>(A, ae, sAq, sEq);  // every lane: the row product, one exponent per component
-        const double tot = apply_field_x<Q>(P, dc, di, A, ae);
-        const double inv = 1.0 / tot;
-        if (tid == 0) {
-            double pv[Q];
-#pragma unroll
-            for (int q = 0; q < Q; ++q) { pv[q] = A[q] * inv; Sacc[q] = (dc ? di : 1.0) * pv[q]; }
-            store_vec<Q>(psi + size_t(i) * Q, pv);
-        }
-        for (uint32_t le = tid; le < d; le += BLOCK) {
-            double m[Q], b[Q], mo[Q], out[Q];
-            load_msg<Q>(Mold, rev[e0 + le], m);
-            load_msg<Q>(Mold, size_t(e0 + le), mo);
-            double didl = 0.0;
-            if (DC2) { const uint32_t l = nbr[e0 + le]; didl = di * double(ndeg[l]); }
-            edge_field<Q, DC2>(P, m, didl, b);
-            double ct = 0.0, cav[Q];
-#pragma unroll
-            for (int q = 0; q < Q; ++q) { cav[q] = (b[q] > 0.0) ? A[q] / b[q] : 0.0; ct += cav[q]; }
-            const double ci = 1.0 / ct;
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const double nv = cav[q] * ci;
-                md = nanmax(md, fabs(mo[q] - nv));
-                out[q] = damp * nv + (1.0 - damp) * mo[q];
-            }
-            store_msg<Q>(Mnew, size_t(e0 + le), out);
-        }
+        return;
     }
-    block_reduce_store<Q>(Sacc, md, sred, partials + size_t(hub_blk[blockIdx.x]) * (Q + 1));
+    double A[Q];
+    int ae[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { A[q] = 1.0; ae[q] = 0; }
+    for (uint32_t x = tid; x < nf; x += BLOCK) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { A[q] *= hf.pA[size_t(f0 + x) * Q + q]; ae[q] += hf.pE[size_t(f0 + x) * Q + q]; }
+        x_norm<Q>(A, ae);
+    }
+    block_product_shfl<Q, BLOCK / 64>(A, ae, sAw, sEw);
+    const double tot = apply_field_x<Q>(P, dc, di, A, ae);
+    const double inv = 1.0 / tot;
+    if (f == f0 && tid == 0) {
+        double pv[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { pv[q] = A[q] * inv; rec[q] = (dc ? di : 1.0) * pv[q]; }
+        store_vec<Q>(psi + size_t(i) * Q, pv);
+    }
+    double md = 0.0;
+    if (le < d) {
+        double b[Q], mo[Q], out[Q], cav[Q];
+        load_vec<Q>(hf.b + (size_t(f) * BLOCK + tid) * Q, b);
+        load_msg<Q>(Mold, size_t(e0 + le), mo);
+        double ct = 0.0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { cav[q] = (b[q] > 0.0) ? A[q] / b[q] : 0.0; ct += cav[q]; }
+        const double ci = 1.0 / ct;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const double nv = cav[q] * ci;
+            md = nanmax(md, fabs(mo[q] - nv));
+            out[q] = damp * nv + (1.0 - damp) * mo[q];
+        }
+        store_msg<Q>(Mnew, size_t(e0 + le), out);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) md = nanmax(md, __shfl_xor(md, o, 64));
+    if ((tid & 63) == 0) smd[tid >> 6] = md;
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int w = 1; w < BLOCK / 64; ++w) md = nanmax(md, smd[w]);
+        atomicMax(reinterpret_cast<unsigned long long *>(rec + Q), (unsigned long long)__double_as_longlong(fabs(md)));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
