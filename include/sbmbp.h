@@ -186,7 +186,7 @@ typedef struct sbmbp_stats {
     double bytes_per_sweep;      /* algorithmic bytes of one sweep */
     uint64_t device_bytes;       /* HBM held by this engine */
     uint32_t n_blocks;           /* workgroups of one sweep launch */
-    uint32_t n_hub_rows;         /* rows above one segment's edge capacity: updated by the hub kernels, not by the frame kernel */
+    uint32_t n_hub_rows;         /* rows above one segment's edge capacity: updated in fragments of 256 edges by launches of their own, not by the frame kernel */
     uint64_t psi_form_sweeps;    /* of `sweeps`, how many ran the marginal-gather form */
     uint64_t hub_edges;          /* directed edges of those rows (sweep_kernel_ms times the frame kernel: it moves the other edges) */
 } sbmbp_stats;
