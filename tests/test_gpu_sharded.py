@@ -334,6 +334,40 @@ def test_three_processes_share_one_gpu(orc, tmp_path, name, world):
     assert abs(float(res["fe"]) - r["f"]) < 2e-9 * max(1.0, abs(r["f"]))
 
 
+def test_bench_multi_rank_line_from_a_bare_shell():
+    """`python bench.py --gpus 2` started as a plain process on this one-GPU box (SBMBP_REHEARSAL=1: both ranks on cuda:0, the C++
+    driver over the callback transport): it launches its own ranks, measures the chunk count (1/2/4/8) in its set-up, and rank 0
+    prints ONE line whose fields the driver reads; the single-engine line of the same workload says the same about the graph"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, SBMBP_REHEARSAL="1")
+    env.pop("SBMBP_SHARD_CHUNKS", None)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "small", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    pr = subprocess.run(cmd, env=env, timeout=600, capture_output=True, text=True, cwd=ROOT)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "strong"
+    assert d["metric"] == "BP edge-message updates/sec" and d["higher_is_better"] is True and d["dtype"] == "f64" and d["vs_baseline"] is None
+    trials = d["config"]["chunk_trials_ms_per_sweep"]
+    assert sorted(trials) == ["1", "2", "4", "8"] and all(v > 0 for v in trials.values())
+    assert str(d["config"]["exchange"]["chunks"]) in trials and d["config"]["exchange"]["transport"] == "callbacks"
+    assert d["converge"]["converged"] is True and d["converge"]["overlap"] > 0.9
+    assert abs(d["value"] - d["steps"] * d["config"]["E2"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+    single = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "small", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
+                            env=env, timeout=600, capture_output=True, text=True, cwd=ROOT)
+    assert single.returncode == 0, single.stderr[-3000:]
+    s1 = json.loads([l for l in single.stdout.splitlines() if l.startswith("{")][-1])
+    assert s1["n_gpus"] == 1 and s1["config"]["E2"] == d["config"]["E2"]
+    assert s1["converge"]["sweeps"] == d["converge"]["sweeps"] and abs(s1["converge"]["overlap"] - d["converge"]["overlap"]) < 1e-9
+
+
 def test_full_size_c3_two_shards_equal_one(S):
     """the headline configuration (N=1e7, Q=4, c=10) cut into two shards with the chunked exchange and the fused send/receive
     buffers: same iterates as one shard, seen through reductions (max difference, overlap, free energy, row sums)"""
