@@ -26,6 +26,10 @@ import sys
 import tempfile
 import time
 
+# the host driver of this pool only supports dmabuf IPC: without this RCCL (and any sharing of device memory between the rank
+# processes) fails with "hipIpcGetMemHandle: invalid argument". Set before anything initialises HIP; an exported value wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

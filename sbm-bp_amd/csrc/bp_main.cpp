@@ -178,6 +178,8 @@ int fail(int code) {
 }  // namespace
 
 int main(int argc, char const *argv[]) {
+    // the host driver of the target pool only supports dmabuf IPC (RCCL between devices fails without it); an exported value wins
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     cmdline var_map = parse(argc, argv);
     if (!var_map.error.empty()) {  // boost::program_options throws: uncaught -> terminate; we report and fail
         std::clog << "bp: " << var_map.error << "\n";
