@@ -47,7 +47,12 @@ struct dev_params {
     int exact;
     int last_exact;            // maxdiff of the last executed sweep is a 1-step difference (not a hint)
     int pad_;
+    // Degree-corrected field factor of the rows of up to FT_D edges: ftab[d][q] = eta[q] exp(-d (h[q] - min h)/N), rewritten with h
+    // by every finalize launch. A row then loads its Q factors (issued before its product loop) instead of evaluating Q
+    // exponentials (4 % of the sweep at Q = 8, dc 1); the entries are the very expression apply_field evaluates, bit for bit.
+    double ftab[(32 + 1) * QMAX];
 };
+constexpr int FT_D = 32;
 // With linear convergence at rate r the 2-step difference of sweep t is (1 + 1/r) times its 1-step difference d_t, and the
 // sweep BEFORE the first one with d_t < crit has a hint below crit (1 + 1/r) / r. The exact criterion must be armed by then, so
 // it is armed at scale * crit with scale = 1.5 (1 + 1/r) / r from the measured ratio of consecutive hints, kept within
@@ -345,7 +350,8 @@ template <int Q> __device__ __forceinline__ int rescale_pow2(double (&A)[Q]) {
 // and, when the spread is still extreme, combined in the log domain with a max-shift exactly as the
 // reference's large-degree path does (bp.cpp:850-868).
 template <int Q>
-__device__ __forceinline__ double apply_field(const dev_params *__restrict__ P, int dc, double di, double (&A)[Q]) {
+__device__ __forceinline__ double apply_field(const dev_params *__restrict__ P, int dc, double di, double (&A)[Q],
+                                              const double *ft = nullptr /* the row's line of P->ftab, already in registers */) {
     double tot = 0.0;
     if (!dc) {
 #pragma unroll
@@ -356,8 +362,13 @@ __device__ __forceinline__ double apply_field(const dev_params *__restrict__ P, 
 #pragma unroll
     for (int q = 1; q < Q; ++q) { hmin = fmin(hmin, P->hN[q]); hmax = fmax(hmax, P->hN[q]); }
     if (di * (hmax - hmin) < 300.0) {
+        if (ft != nullptr) {
 #pragma unroll
-        for (int q = 0; q < Q; ++q) { A[q] *= P->eta[q] * exp(-di * (P->hN[q] - hmin)); tot += A[q]; }
+            for (int q = 0; q < Q; ++q) { A[q] *= ft[q]; tot += A[q]; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { A[q] *= P->eta[q] * exp(-di * (P->hN[q] - hmin)); tot += A[q]; }
+        }
     } else {
         double lp[Q], m = -1.0e300;
 #pragma unroll
@@ -600,7 +611,8 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
     double Sacc[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) Sacc[q] = 0.0;
-    auto finish_row = [&](int r, double di, double (&A)[Q], const int *ae /* per-component exponents of a long row, or null */) {
+    auto finish_row = [&](int r, double di, double (&A)[Q], const int *ae /* per-component exponents of a long row, or null */,
+                          const double *ft = nullptr /* the row's line of P->ftab (rows of <= FT_D edges under dc), or null */) {
         double pv[Q];
         double tot;
         if (ae) {
@@ -609,7 +621,7 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
             for (int q = 0; q < Q; ++q) x[q] = ae[q];
             tot = apply_field_x<Q>(P, dc, di, A, x);
         } else {
-            tot = apply_field<Q>(P, dc, di, A);
+            tot = apply_field<Q>(P, dc, di, A, ft);
         }
         store_vec<Q>(&sA[r * Q], A);
         const double inv = 1.0 / tot;
@@ -629,7 +641,9 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
 #pragma unroll
             for (int q = 0; q < Q; ++q) Sacc[q] += gi * pv[q];
         } else if (ee - es <= BIG_ROW) {
-            double A[Q];
+            double A[Q], ft[Q];
+            const bool tab = dc != 0 && ee - es <= FT_D;  // the field factors of this degree: loaded while the product runs
+            if (tab) load_vec<Q>(P->ftab + size_t(ee - es) * QMAX, ft);
 #pragma unroll
             for (int q = 0; q < Q; ++q) A[q] = 1.0;
             for (int e = es; e < ee; ++e) {
@@ -639,7 +653,7 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
                 for (int q = 0; q < Q; ++q) A[q] *= b[q];
                 rescale_pow2<Q>(A);
             }
-            finish_row(r, di, A, nullptr);
+            finish_row(r, di, A, nullptr, tab ? ft : nullptr);
         }
     }
     if (sbig)  // uniform: written before the barrier that ends phase 1
@@ -730,7 +744,7 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
 // run-time Q and local arrays indexed by it the same code lived in scratch memory and took 6 (Q = 2) to 21 us (Q = 8).
 template <int Q>
 __device__ __forceinline__ void finalize_update(dev_params *__restrict__ P, const double *sums /* [Q] then the max */, int mode,
-                                                double *__restrict__ diff_hist, uint32_t hist_cap, int md_exact) {
+                                                double *__restrict__ diff_hist, uint32_t hist_cap, int md_exact, double *s_hN /* LDS [Q]: h/N for field_table */) {
     double cab[Q * Q], eta[Q], Sold[Q], S[Q];
 #pragma unroll
     for (int a = 0; a < Q * Q; ++a) cab[a] = P->cab[a];
@@ -754,7 +768,7 @@ __device__ __forceinline__ void finalize_update(dev_params *__restrict__ P, cons
         etaF[q1] = eta[q1] * exp(-beta * hN[q1]);
     }
 #pragma unroll
-    for (int q = 0; q < Q; ++q) { P->S[q] = S[q]; P->hN[q] = hN[q]; P->etaF[q] = etaF[q]; }
+    for (int q = 0; q < Q; ++q) { P->S[q] = S[q]; P->hN[q] = hN[q]; P->etaF[q] = etaF[q]; s_hN[q] = hN[q]; }
     P->have_prev = 1;
     if (mode == 0) {
         const double md = sums[Q];
@@ -775,6 +789,18 @@ __device__ __forceinline__ void finalize_update(dev_params *__restrict__ P, cons
             P->stop = 1;
         }
         P->sweep_idx = it + 1;
+    }
+}
+
+// the whole workgroup, after finalize_update and a barrier: P->ftab from the new h (dev_params)
+template <int Q>
+__device__ __forceinline__ void field_table(dev_params *__restrict__ P, const double *s_hN) {
+    double hmin = s_hN[0];
+#pragma unroll
+    for (int q = 1; q < Q; ++q) hmin = fmin(hmin, s_hN[q]);
+    for (int x = threadIdx.x; x < (FT_D + 1) * Q; x += BLOCK) {
+        const int d = x / Q, q = x - d * Q;
+        P->ftab[d * QMAX + q] = P->eta[q] * exp(-double(d) * (s_hN[q] - hmin));
     }
 }
 
@@ -961,7 +987,8 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
 #pragma unroll
     for (int q = 0; q < Q; ++q) Sacc[q] = 0.0;
     double md = 0.0;
-    auto finish_row = [&](int r, double di, double (&A)[Q], const int *ae /* per-component exponents of a long row, or null */) {
+    auto finish_row = [&](int r, double di, double (&A)[Q], const int *ae /* per-component exponents of a long row, or null */,
+                          const double *ft = nullptr /* the row's line of P->ftab (rows of <= FT_D edges under dc), or null */) {
         double pv[Q];
         double tot;
         if (ae) {
@@ -970,7 +997,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
             for (int q = 0; q < Q; ++q) x[q] = ae[q];
             tot = apply_field_x<Q>(P, dc, di, A, x);
         } else {
-            tot = apply_field<Q>(P, dc, di, A);
+            tot = apply_field<Q>(P, dc, di, A, ft);
         }
         if (!SHARD) store_vec<Q>(&sA[r * Q], A);
         const double inv = 1.0 / tot;
@@ -1005,7 +1032,9 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
 #pragma unroll
             for (int q = 0; q < Q; ++q) Sacc[q] += gi * pv[q];
         } else if (ee - es <= BIG_ROW) {
-            double A[Q];
+            double A[Q], ft[Q];
+            const bool tab = dc != 0 && ee - es <= FT_D;  // the field factors of this degree: loaded while the product runs
+            if (tab) load_vec<Q>(P->ftab + size_t(ee - es) * QMAX, ft);
 #pragma unroll
             for (int q = 0; q < Q; ++q) A[q] = 1.0;
             for (int e = es; e < ee; ++e) {
@@ -1015,7 +1044,7 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
                 for (int q = 0; q < Q; ++q) A[q] *= b[q];
                 rescale_pow2<Q>(A);
             }
-            finish_row(r, double(ee - es), A, nullptr);
+            finish_row(r, double(ee - es), A, nullptr, tab ? ft : nullptr);
         }
     }
     if (sbig)  // uniform: written before the barrier that ends phase 1
@@ -1458,8 +1487,11 @@ k_finalize(const double *__restrict__ partials, uint32_t n_part, int mode, dev_p
     if (mode == 0 && P->stop) return;
     __shared__ double sacc[(BLOCK / 64) * (Q + 1)];
     __shared__ double sout[Q + 1];
+    __shared__ double s_hN[Q];
     fold_rows<Q, false>(partials, 0, n_part, sacc, sout);
-    if (threadIdx.x == 0) finalize_update<Q>(P, sout, mode, diff_hist, hist_cap, md_exact);
+    if (threadIdx.x == 0) finalize_update<Q>(P, sout, mode, diff_hist, hist_cap, md_exact, s_hN);
+    __syncthreads();
+    field_table<Q>(P, s_hN);
 }
 
 // K2 with its fold in ONE launch (single engine, after a sweep): workgroup b folds the contiguous chunk b of the sweep's
@@ -1509,7 +1541,10 @@ k_fold_finalize(const double *__restrict__ partials, uint32_t n_part, uint32_t c
         fold_rows<Q, true>(stage, 0, gridDim.x, sacc, sout);
         if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     }
-    if (tid == 0) finalize_update<Q>(P, sout, 0, diff_hist, hist_cap, md_exact);
+    __shared__ double s_hN[Q];
+    if (tid == 0) finalize_update<Q>(P, sout, 0, diff_hist, hist_cap, md_exact, s_hN);
+    __syncthreads();  // (uniform: only the last workgroup is still here)
+    field_table<Q>(P, s_hN);
 }
 
 // ------------------------------------------------------------------------------------------------
