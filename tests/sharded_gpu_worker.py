@@ -1,5 +1,6 @@
 """worker of tests/test_gpu_sharded.py::test_three_processes_share_one_gpu (launched by torch.distributed.run):
-one rank of the C++ driver per process, all on cuda:0, the callback transport over gloo (buffers staged through the host)."""
+one rank of the C++ driver per process, all on cuda:0, the callback transport over gloo (buffers staged through the host);
+with a third argument "rccl" (test_two_processes_two_gpus_over_rccl): one GPU per rank and the library's RCCL communicators."""
 import os
 import sys
 
@@ -20,17 +21,19 @@ from sbm_bp_amd.distributed import Comm, ShardedBP  # noqa: E402
 
 def main():
     out, name = sys.argv[1], sys.argv[2]
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo")
+    rccl = len(sys.argv) > 3 and sys.argv[3] == "rccl"
+    device = int(os.environ.get("LOCAL_RANK", "0")) if rccl else 0
+    torch.cuda.set_device(device)
+    dist.init_process_group("nccl" if rccl else "gloo")
     a = args_of(golden(name))
     g = orc.Graph.from_edgelist(a["path"], a["N"])
     bp = orc.OracleBP(g, a["Q"], a["dc"])
     bp.init_messages(0, None, a["true_conf"], orc.Rng(a["seed"]))
     cab, na = orc.param_from_direct(a["N"], a["Q"], a["pa"], a["cab_upper"])
     psi0, msg0 = bp.get_state()
-    comm = Comm.callbacks_from_torch()
-    sb = ShardedBP(S.Graph.from_csr(g.row_ptr, g.nbr), a["Q"], a["dc"], comm, device=0)
-    assert sb.info.n_chunks == 4 and comm.transport == "callbacks"  # the chunked exchange of the multi-rank path
+    comm = Comm.rccl_from_torch(device) if rccl else Comm.callbacks_from_torch()
+    sb = ShardedBP(S.Graph.from_csr(g.row_ptr, g.nbr), a["Q"], a["dc"], comm, device=device)
+    assert sb.info.n_chunks == 4 and comm.transport == ("rccl" if rccl else "callbacks")  # the chunked exchange of the multi-rank path
     e0 = int(g.row_ptr[sb.row0])
     sb.init_messages_device(7, a["true_conf"])
     sb.set_state(psi0[sb.row0:sb.row0 + sb.n_own], msg0[e0:e0 + sb.n_edges])
@@ -42,7 +45,7 @@ def main():
     ent = sb.compute_entropy()
     psi_local = sb.get_state()[0]
     gathered = [None] * comm.world
-    dist.all_gather_object(gathered, psi_local)
+    dist.all_gather_object(gathered, psi_local)  # (pickled through the process group: works on either backend)
     if comm.rank == 0:
         np.savez(out, d3=d3, niter=niter, exact=exact, overlap=ov, fe=fe, entropy=ent, psi=np.concatenate(gathered))
     sb.close()

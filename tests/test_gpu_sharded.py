@@ -334,6 +334,35 @@ def test_three_processes_share_one_gpu(orc, tmp_path, name, world):
     assert abs(float(res["fe"]) - r["f"]) < 2e-9 * max(1.0, abs(r["f"]))
 
 
+def test_two_processes_two_gpus_over_rccl(S, orc, tmp_path):
+    """the production transport with more than one rank: two processes, one GPU each, the library's own RCCL communicators
+    (grouped ncclSend/ncclRecv per chunk, all-gather of the fold rows). Needs two devices: skipped on the one-GPU boxes this
+    repository is developed on, there for the first node that has them. Result = the run with the ranks as threads."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    if S.load_library().sbmbp_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from bench import free_port
+    name, world = "q4_tight_seed0", 2
+    out = tmp_path / "result.npz"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "sharded_gpu_worker.py"), str(out), name, "rccl"]
+    pr = subprocess.run(cmd, env=env, timeout=600, capture_output=True, text=True)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    res = np.load(out)
+    a, r, g, cab, na, psi0, msg0 = _problem(orc, name)
+    ref = _sharded(g, a, cab, na, psi0, msg0, world)
+    assert abs(ref.sweep(3) - float(res["d3"])) < 1e-15
+    niter, exact = ref.converge(1e-12, 3000, 1.0, check_every=6)
+    assert int(res["niter"]) == niter
+    assert np.abs(res["psi"] - ref.global_state()[0]).max() < 1e-14
+    assert abs(float(res["fe"]) - ref.compute_free_energy()) < 1e-13 and abs(float(res["fe"]) - r["f"]) < 2e-9 * max(1.0, abs(r["f"]))
+
+
 def test_bench_multi_rank_line_from_a_bare_shell():
     """`python bench.py --gpus 2` started as a plain process on this one-GPU box (SBMBP_REHEARSAL=1: both ranks on cuda:0, the C++
     driver over the callback transport): it launches its own ranks, measures the chunk count (1/2/4/8) in its set-up, and rank 0
