@@ -42,7 +42,7 @@ WORKLOADS = {
     # ten times C3 on one GPU (E2 = 1e9 < 2^32; ~63 GB of the 288 GB): not a SURVEY configuration, a capacity check
     "C3x10": (100_000_000, 4, 10.0, 0.1, 0, 2),
     "C3x20": (200_000_000, 4, 10.0, 0.1, 0, 2),  # capacity: E2 = 2.0e9 directed edges, ~126 GB of HBM
-    # degree-corrected SBM, power-law propensities, --deg_corr_flag 1 (hub rows take the workgroup-per-row kernel)
+    # degree-corrected SBM, power-law propensities, --deg_corr_flag 1 (hub rows: fragments of 256 edges, two launches of their own)
     "C4": (1_000_000, 8, 8.0, 0.1, 1, 3),
     # the same Q and mean degree as C4 on a plain planted partition (Poisson degrees): separates what Q = 8 costs from what the
     # power-law degrees cost
