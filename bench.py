@@ -285,8 +285,12 @@ def main():
         chunk_trials = None
         if world > 1 and not os.environ.get("SBMBP_SHARD_CHUNKS"):
             chunk_trials, runner, graph = {}, None, None
-            for nc in (1, 2, 4, 8):
-                cand = ShardedBP.synthetic(N, Q, c, eps, gseed, dc=dc, seed=1234, comm=comm, device=local_rank, n_chunks=nc, graph=graph)
+            # "2p" / "4p": the same chunk counts with stream priorities (SBMBP_SHARD_PRIO=1: chunks complete one after the other
+            # and their halo leaves earlier, at 6 - 10 % more kernel time); the library reads the switch when a plan is created
+            for nc in (1, 2, 4, 8, "2p", "4p"):
+                os.environ["SBMBP_SHARD_PRIO"] = "1" if str(nc).endswith("p") else "0"
+                cand = ShardedBP.synthetic(N, Q, c, eps, gseed, dc=dc, seed=1234, comm=comm, device=local_rank,
+                                           n_chunks=int(str(nc).rstrip("p")), graph=graph)
                 graph = cand.graph
                 cand.sweep(2, 1.0, want_diff=False)
                 best_try = None
@@ -397,6 +401,7 @@ def main():
                 out["config"]["comm_fallback"] = comm_note
             if chunk_trials:
                 out["config"]["chunk_trials_ms_per_sweep"] = {str(k): round(v, 4) for k, v in chunk_trials.items()}
+                out["config"]["chunk_choice"] = str(best_nc)
             out["config"]["exchange"] = {"transport": runner.comm.transport, "chunks": int(info.n_chunks),
                                          "payload_components": int(info.halo_components), "halo_rows": int(info.n_halo),
                                          "sent_MB_per_sweep": round(float(per_peer.sum()), 2),
