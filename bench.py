@@ -287,10 +287,13 @@ def main():
             chunk_trials, runner, graph = {}, None, None
             # "2p" / "4p": the same chunk counts with stream priorities (SBMBP_SHARD_PRIO=1: chunks complete one after the other
             # and their halo leaves earlier, at 6 - 10 % more kernel time); the library reads the switch when a plan is created
-            for nc in (1, 2, 4, 8, "2p", "4p"):
+            # "2s" / "4s": all chunks on one stream (SBMBP_SHARD_STREAMS=1): they complete strictly one after the other, without
+            # the second stream that fills their tails
+            for nc in (1, 2, 4, 8, "2p", "4p", "2s", "4s"):
                 os.environ["SBMBP_SHARD_PRIO"] = "1" if str(nc).endswith("p") else "0"
+                os.environ["SBMBP_SHARD_STREAMS"] = "1" if str(nc).endswith("s") else "2"
                 cand = ShardedBP.synthetic(N, Q, c, eps, gseed, dc=dc, seed=1234, comm=comm, device=local_rank,
-                                           n_chunks=int(str(nc).rstrip("p")), graph=graph)
+                                           n_chunks=int(str(nc).rstrip("ps")), graph=graph)
                 graph = cand.graph
                 cand.sweep(2, 1.0, want_diff=False)
                 best_try = None
