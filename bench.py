@@ -314,6 +314,8 @@ def main():
                     runner, best_nc = cand, nc
                 else:
                     cand.close()
+            os.environ["SBMBP_SHARD_PRIO"] = "1" if str(best_nc).endswith("p") else "0"  # (what the chosen plan was created with)
+            os.environ["SBMBP_SHARD_STREAMS"] = "1" if str(best_nc).endswith("s") else "2"
             runner.init_messages_device(1234, tc)
             runner.expand_bp_params(runner.cab, runner.na, 1.0)
         else:
