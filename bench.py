@@ -285,11 +285,12 @@ def main():
         chunk_trials = None
         if world > 1 and not os.environ.get("SBMBP_SHARD_CHUNKS"):
             chunk_trials, runner, graph = {}, None, None
-            # "2p" / "4p": the same chunk counts with stream priorities (SBMBP_SHARD_PRIO=1: chunks complete one after the other
+            # "4p": four chunks with stream priorities (SBMBP_SHARD_PRIO=1: chunks complete one after the other
             # and their halo leaves earlier, at 6 - 10 % more kernel time); the library reads the switch when a plan is created
-            # "2s" / "4s": all chunks on one stream (SBMBP_SHARD_STREAMS=1): they complete strictly one after the other, without
+            # "4s": four chunks on one stream (SBMBP_SHARD_STREAMS=1): they complete strictly one after the other, without
             # the second stream that fills their tails
-            for nc in (1, 2, 4, 8, "2p", "4p", "2s", "4s"):
+            # (a plan costs 3 s per rank at 8 ranks of C3 and 12 s at 2 ranks: six candidates)
+            for nc in (1, 2, 4, 8, "4p", "4s"):
                 os.environ["SBMBP_SHARD_PRIO"] = "1" if str(nc).endswith("p") else "0"
                 os.environ["SBMBP_SHARD_STREAMS"] = "1" if str(nc).endswith("s") else "2"
                 cand = ShardedBP.synthetic(N, Q, c, eps, gseed, dc=dc, seed=1234, comm=comm, device=local_rank,
