@@ -62,6 +62,12 @@ struct bp_t {
     std::vector<double> na_expect, nna_expect, cab_expect;
     std::vector<double> Sprev;  // previous sweep's sum_i g_i psi_i (field relaxation of the synchronous schedule)
     double field_mix = 1.0;
+    // bookkeeping of the synchronous twin (mirrors the engine, not the reference): which sweep form the engine would run
+    unsigned init_flag = 0;       // flag of the last init_messages (1/3: clamped rows are one-hot)
+    bool consistent = false;      // psi holds the marginals of the message pair (an undamped sweep ran since the last change)
+    bool msg_form_only = false;   // the engine was told to gather messages (sbmbp_set_gather_mode 1)
+    bool auto_relax = true;       // adaptive relaxation of converge_sync
+    int ar_fl = 0, ar_gl = -1;    // levels reached by the last converge_sync
     const unsigned LARGE_DEGREE = 50;  // belief_propagation.h:68
     const double EPS = 1.0e-50;        // belief_propagation.h:69
 };
@@ -125,6 +131,7 @@ bool load_edge_pairs(const char *path, std::vector<uint32_t> &pairs) {
 void set_params(bp_t &s, const double *cab, const uint32_t *na, double beta) {
     uint32_t Q = s.Q;
     s.beta = beta;
+    s.consistent = false;
     s.cab.assign(cab, cab + Q * Q);
     s.na.assign(na, na + Q);
     s.logcab.resize(Q * Q);
@@ -188,6 +195,8 @@ void init_messages(bp_t &s, unsigned flag, const int32_t *conf, const uint32_t *
         for (uint64_t k = g.row_ptr[i]; k < g.row_ptr[i + 1]; ++k) fill(&s.M[k * Q]);
     }
     if (flag == 0) s.planted.assign(N, -1);  // B6: with -i 0 the planted vector is never stored
+    s.init_flag = flag;
+    s.consistent = false;
 }
 
 inline double gweight(const bp_t &s, uint32_t i) { return s.dc == 0 ? 1.0 : double(s.g->deg(i)); }
@@ -483,17 +492,163 @@ double sweep_sync(bp_t &s, double damp) {
         }
     }
     s.M.swap(s.Mnew);
+    {   // engine.hip run_sweeps: psi_consistent after an executed sweep
+        bool clamp = false, wpos = true;
+        for (int32_t p : s.planted) if (p != -1) { clamp = true; break; }
+        for (double c : s.cab) if (!(c > 0.0)) wpos = false;
+        s.consistent = damp == 1.0 && (!clamp || s.init_flag == 1 || s.init_flag == 3) && wpos;
+    }
     return maxdiff;
 }
 
-int converge_sync(bp_t &s, double crit, unsigned max_iter, double damp, double *last_diff) {
-    for (int it = 0; it < int(max_iter); ++it) {
-        double d = sweep_sync(s, damp);
-        if (last_diff) *last_diff = d;
-        if (d < crit) { compute_h_full(s); return it; }
+// ---- adaptive relaxation of the synchronous schedule (no reference counterpart) ----------------
+// The reference's random-sequential sweep keeps h_ current inside a sweep (:1088-1095) and never updates two neighbours at
+// once; Jacobi sweeps can oscillate where it converges. converge_sync therefore watches three signatures and relaxes the
+// schedule when one shows (the fixed points do not move): (F) the raw field sums swing with period 2, (P) the messages do
+// (2-step difference far below the 1-step difference), (W) no progress over a window of sweeps. This restates, on the CPU,
+// the state machine the engine runs on the device (kernels.h finalize_update) so that both stop on the same sweep.
+struct ar_t {
+    static constexpr int NF = 4, NG = 5, WIN = 24;
+    const double FIELD[NF] = {1.0, 0.25, 0.1, 0.05};
+    const double GMIX[NG] = {0.5, 0.5, 0.25, 0.25, 0.1};
+    const double GDAMP[NG] = {1.0, 0.5, 0.5, 0.25, 0.25};
+    bool on = true, psi_ok = false;
+    double crit = 0, base_mix = 1.0;
+    int fl = 0, gl = -1;
+    bool armed = false, probing = false;
+    int stall = 0, hold = 0, holdS = 0, sigc = 0, nS = 0, wn = 0;
+    double v1 = -1, v2 = -1, wmin = 1e300, pmin = -1, d1p = -1, prev_hint = 0;
+    std::vector<double> S1, S2;
+    double mix() const { double m = std::min(base_mix, FIELD[fl]); return gl >= 0 ? std::min(m, GMIX[gl]) : m; }
+    double damp() const { return gl >= 0 ? GDAMP[gl] : 1.0; }
+    bool psi_form() const { return psi_ok && damp() == 1.0; }
+    // what the next sweep reports: 1 = 1-step difference, 2 = 2-step difference
+    int kind_next(bool explicit_first) const {
+        int k = (!psi_form() || armed || explicit_first) ? 1 : 2;
+        return probing ? 3 - k : k;
     }
+    void reset_after() {
+        hold = 6; stall = 0; v1 = v2 = -1; prev_hint = 0; probing = false; armed = false;
+        wn = 0; wmin = 1e300; pmin = -1; nS = 0; sigc = 0; d1p = -1; holdS = 4;
+    }
+    void esc_gen() {
+        if (gl + 1 >= NG) { hold = 1 << 30; return; }
+        ++gl; reset_after();
+    }
+    void esc_field() {
+        int nf = fl;
+        while (nf + 1 < NF && !(FIELD[nf] < mix())) ++nf;   // the next cap that actually lowers the mix
+        if (FIELD[nf] < mix()) { fl = nf; reset_after(); }
+        else esc_gen();
+    }
+    // after sweep `it`: v = reported difference of kind `kind`, Sraw = unrelaxed sums of the new marginals. Returns true when
+    // the run has converged. `was_psi`: the sweep ran in the marginal-gather form.
+    bool after_sweep(double v, int kind, const std::vector<double> &Sraw, bool was_psi) {
+        bool conv = false, esc = false;
+        if (!on) {
+            if (kind == 1) conv = v < crit;
+            else { hint(v); }
+            return conv;
+        }
+        if (probing) {
+            probing = false;
+            if (kind == 1 && v < crit) conv = true;
+            else if (v1 >= 0) {
+                const double one = kind == 1 ? v : v1, two = kind == 1 ? v1 : v;
+                if (two < 0.5 * one) { esc_gen(); esc = true; }
+                else { hold = 8; stall = 0; }
+            }
+        } else {
+            if (kind == 1) {
+                if (v < crit) conv = true;
+                else if (was_psi && prev_hint > 0) {  // first 1-step value after the hints armed the exact criterion
+                    if (prev_hint < 0.5 * v) { esc_gen(); esc = true; }
+                    else prev_hint = 0;
+                }
+            } else hint(v);
+            if (!conv && !esc) {
+                if (hold > 0) --hold;
+                else {
+                    if (v2 >= 0 && v >= 0.98 * v2) ++stall; else stall = 0;
+                    if (stall >= 4) { probing = true; stall = 0; }
+                }
+                v2 = v1; v1 = v;
+                wmin = std::min(wmin, v); ++wn;
+                if (wn >= WIN * (1 + std::max(0, gl))) {
+                    if (pmin >= 0 && wmin >= 0.9 * pmin && hold < (1 << 29)) { esc_gen(); esc = true; }
+                    else { pmin = wmin; wmin = 1e300; wn = 0; }
+                }
+            }
+        }
+        if (conv || esc) return conv;
+        // (F) period 2 in the raw field sums
+        const size_t Q = Sraw.size();
+        if (holdS > 0) { --holdS; S2 = S1; S1 = Sraw; nS = std::min(nS + 1, 2); return false; }
+        bool fe = false;
+        if (nS >= 2) {
+            double d1 = 0, d2 = 0, tot = 0;
+            for (size_t q = 0; q < Q; ++q) { d1 = std::max(d1, std::fabs(Sraw[q] - S1[q])); d2 = std::max(d2, std::fabs(Sraw[q] - S2[q])); tot += std::fabs(Sraw[q]); }
+            const bool sig = d2 < 0.5 * d1 && d1 > 1e-9 * tot;
+            if (sig && d1 > 0.05 * tot) fe = true;
+            else if (sig && (d1p < 0 || d1 >= 0.9 * d1p)) { if (++sigc >= 6) fe = true; }
+            else sigc = 0;
+            d1p = d1;
+        }
+        S2 = S1; S1 = Sraw; nS = std::min(nS + 1, 2);
+        if (fe) esc_field();
+        return false;
+    }
+    void hint(double v) {  // a 2-step value can only arm the exact criterion (kernels.h HINT_SCALE)
+        double scale = 8.0;
+        if (prev_hint > 0 && v > 0 && v < prev_hint) { const double r = v / prev_hint; scale = std::min(64.0, std::max(8.0, 1.5 * (1.0 + 1.0 / r) / r)); }
+        prev_hint = v;
+        if (v < scale * crit) armed = true;
+    }
+};
+
+// would the engine run this configuration in the marginal-gather form (engine.hip psi_form_allowed)?
+bool engine_psi_form(const bp_t &s, double damp) {
+    bool clamp = false;
+    for (int32_t p : s.planted) if (p != -1) { clamp = true; break; }
+    bool wpos = true;
+    for (double c : s.cab) if (!(c > 0.0)) wpos = false;
+    const bool onehot = s.init_flag == 1 || s.init_flag == 3;
+    return !s.msg_form_only && damp == 1.0 && (!clamp || onehot) && s.dc != 2 && wpos && s.g->E2() > 0;
+}
+
+int converge_sync(bp_t &s, double crit, unsigned max_iter, double damp, double *last_diff) {
+    ar_t ar;
+    ar.on = s.auto_relax && crit >= 0;
+    ar.crit = crit;
+    ar.base_mix = s.field_mix;
+    ar.psi_ok = engine_psi_form(s, damp);
+    const bool first_explicit = !s.consistent;
+    const double keep_mix = s.field_mix;
+    const uint32_t Q = s.Q;
+    std::vector<double> Sraw(Q);
+    int result = -1;
+    for (int it = 0; it < int(max_iter); ++it) {
+        const bool was_psi = ar.psi_form() && !(it == 0 && first_explicit);
+        const int kind = ar.kind_next(it == 0 && first_explicit && !ar.probing);
+        s.field_mix = ar.mix();
+        std::vector<double> Mold;
+        if (kind == 2) Mold = s.Mnew;  // m^{t-1}: what the sweep before last left in the buffer this sweep overwrites
+        const double d1 = sweep_sync(s, damp * ar.damp());
+        double v = d1;
+        if (kind == 2) {
+            v = 0.0;
+            if (Mold.size() == s.M.size()) { for (size_t k = 0; k < s.M.size(); ++k) { const double x = std::fabs(s.M[k] - Mold[k]); if (x > v || x != x) v = x; } }
+            else v = d1;
+        }
+        if (last_diff) *last_diff = d1;
+        std::fill(Sraw.begin(), Sraw.end(), 0.0);
+        for (uint32_t i = 0; i < s.N; ++i) { const double gi = gweight(s, i); for (uint32_t q = 0; q < Q; ++q) Sraw[q] += gi * s.psi[size_t(i) * Q + q]; }
+        if (ar.after_sweep(v, kind, Sraw, was_psi)) { result = it; break; }
+    }
+    s.ar_fl = ar.fl; s.ar_gl = ar.gl;
+    s.field_mix = keep_mix;
     compute_h_full(s);
-    return -1;
+    return result;
 }
 
 // ---- free energy (:442-504, :562-612, :675-709, :744-750) --------------------------------------
@@ -922,11 +1077,18 @@ void orc_bp_set_state(void *sp, const double *psi, const double *msg_out) {
     auto &s = *static_cast<bp_t *>(sp);
     if (psi) std::copy(psi, psi + s.psi.size(), s.psi.begin());
     if (msg_out) std::copy(msg_out, msg_out + s.M.size(), s.M.begin());
+    s.consistent = false;
+    s.init_flag = 0;  // an arbitrary state: clamped rows are no longer known to be one-hot
 }
 void orc_bp_get_h(void *sp, double *h) { auto &s = *static_cast<bp_t *>(sp); std::copy(s.h.begin(), s.h.end(), h); }
 void orc_bp_init_h(void *sp) { init_h(*static_cast<bp_t *>(sp)); }
 void orc_bp_compute_h(void *sp) { compute_h_full(*static_cast<bp_t *>(sp)); }
 void orc_bp_set_field_mix(void *sp, double a) { static_cast<bp_t *>(sp)->field_mix = a; static_cast<bp_t *>(sp)->Sprev.clear(); }
+// the same without forgetting the previous sums (a schedule that lowers the mix in the middle of a run)
+void orc_bp_set_field_mix_keep(void *sp, double a) { static_cast<bp_t *>(sp)->field_mix = a; }
+void orc_bp_set_auto_relax(void *sp, int on) { static_cast<bp_t *>(sp)->auto_relax = on != 0; }
+void orc_bp_set_msg_form(void *sp, int on) { static_cast<bp_t *>(sp)->msg_form_only = on != 0; }
+void orc_bp_ar_levels(void *sp, int *fl, int *gl) { *fl = static_cast<bp_t *>(sp)->ar_fl; *gl = static_cast<bp_t *>(sp)->ar_gl; }
 double orc_bp_node_update(void *sp, uint32_t i, double damp, int large) {
     auto &s = *static_cast<bp_t *>(sp);
     return large ? node_update_large(s, i, damp) : node_update_small(s, i, damp);

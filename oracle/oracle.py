@@ -53,6 +53,10 @@ def lib():
             "orc_bp_init_h": (None, [C.c_void_p]),
             "orc_bp_compute_h": (None, [C.c_void_p]),
             "orc_bp_set_field_mix": (None, [C.c_void_p, C.c_double]),
+            "orc_bp_set_field_mix_keep": (None, [C.c_void_p, C.c_double]),
+            "orc_bp_set_auto_relax": (None, [C.c_void_p, C.c_int]),
+            "orc_bp_set_msg_form": (None, [C.c_void_p, C.c_int]),
+            "orc_bp_ar_levels": (None, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
             "orc_bp_node_update": (C.c_double, [C.c_void_p, C.c_uint32, C.c_double, C.c_int]),
             "orc_bp_converge_async": (C.c_int, [C.c_void_p, C.c_float, C.c_uint, C.c_float, C.c_void_p, C.c_int]),
             "orc_bp_sweep_sync": (C.c_double, [C.c_void_p, C.c_double]),
@@ -196,6 +200,24 @@ class OracleBP:
     def set_field_mix(self, alpha):
         """relaxation of the global field in the synchronous schedule: S <- (1-alpha) S_prev + alpha sum_i g_i psi_i"""
         lib().orc_bp_set_field_mix(self._h, alpha)
+
+    def set_field_mix_keep(self, alpha):
+        """as set_field_mix, but the previous sweep's sums stay (a change of the mix in the middle of a run)"""
+        lib().orc_bp_set_field_mix_keep(self._h, alpha)
+
+    def set_auto_relax(self, on):
+        """adaptive relaxation of converge_sync (the engine's default schedule); off = plain Jacobi sweeps"""
+        lib().orc_bp_set_auto_relax(self._h, int(on))
+
+    def set_msg_form(self, on):
+        """mirror of sbmbp_set_gather_mode(1): every sweep reports 1-step differences"""
+        lib().orc_bp_set_msg_form(self._h, int(on))
+
+    def ar_levels(self):
+        """(field level, generic level) the last converge_sync ended on; (0, -1) = it never relaxed"""
+        a, b = C.c_int(0), C.c_int(0)
+        lib().orc_bp_ar_levels(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def node_update(self, i, damp=1.0, large=False):
         return lib().orc_bp_node_update(self._h, i, damp, int(large))
