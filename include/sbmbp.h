@@ -120,6 +120,17 @@ int sbmbp_get_field(sbmbp_engine_t *e, double *h /* Q */); /* h_ of belief_propa
  * convergence flag (the returned niter is exact regardless). */
 int sbmbp_set_schedule(sbmbp_engine_t *e, double field_mix, uint32_t check_every);
 
+/* Adaptive relaxation of converge / inference / learning (on by default; no reference counterpart). The reference sweeps
+ * random-sequentially and keeps h_ current inside a sweep (belief_propagation.cpp:394-401, 1088-1095); synchronous sweeps can
+ * oscillate where it converges. With this on, the device-side convergence logic watches for (F) a period-2 swing of the
+ * field sums, (P) a period-2 swing of the messages, (W) a window of sweeps without progress, and lowers field_mix
+ * (1 -> 0.25 -> 0.1 -> 0.05) or moves down a (field_mix cap, damping factor) ladder ((0.5,1), (0.25,1), (0.5,0.5),
+ * (0.25,0.5), (0.1,0.5), (0.25,0.25), (0.1,0.25)); the fixed points do not move, and runs that never oscillate are untouched. Fixed sweep
+ * counts (sbmbp_sweep) are never relaxed. sbmbp_get_relaxation reports where the last converge call ended
+ * (field level 0 and generic level -1: it never relaxed). */
+int sbmbp_set_auto_relax(sbmbp_engine_t *e, int on);
+int sbmbp_get_relaxation(const sbmbp_engine_t *e, int *field_level, int *generic_level, double *field_mix, double *damping_factor);
+
 /* Which form of the sweep kernel runs. 0 = automatic: incoming messages are reconstructed from the
  * neighbours' marginals (same iterates, cache-friendly gather) whenever that is exact — damping 1,
  * every cab entry > 0, no clamped rows, deg_corr_flag != 2 — with the reference's 1-step message
@@ -233,6 +244,9 @@ typedef struct sbmbp_conv_state {
     int sweep_idx;  /* sweeps executed since sbmbp_shard_begin */
     int stop;       /* queued sweeps after the trigger were skipped */
     int last_exact;
+    int pause;      /* with stop: adaptive relaxation asked for damping; answer with sbmbp_shard_resume and go on in the
+                       message-gather form from sweep_idx */
+    int ar_field_level, ar_generic_level; /* levels of the adaptive relaxation (sbmbp_get_relaxation) */
 } sbmbp_conv_state;
 
 int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *desc, uint32_t Q, uint32_t deg_corr_flag, int device);
@@ -317,6 +331,7 @@ int sbmbp_shard_poll(sbmbp_engine_t *e, sbmbp_conv_state *out);
  * wait blocks until that copy has landed (the caller may queue the next batch in between) */
 int sbmbp_shard_state_record(sbmbp_engine_t *e, int slot);
 int sbmbp_shard_state_wait(sbmbp_engine_t *e, int slot, sbmbp_conv_state *out);
+int sbmbp_shard_resume(sbmbp_engine_t *e);
 /* after a poll: `executed` sweeps of the queued batch really ran; flips the buffer parities */
 int sbmbp_shard_commit(sbmbp_engine_t *e, uint32_t executed);
 /* ---------------------------------------------------------------------------------------------
@@ -388,6 +403,8 @@ int sbmbp_dist_get_params(sbmbp_dist_t *d, double *cab, uint32_t *na);
 int sbmbp_dist_set_schedule(sbmbp_dist_t *d, double field_mix, uint32_t check_every);
 int sbmbp_dist_set_learning_schedule(sbmbp_dist_t *d, double field_mix, double snap);
 int sbmbp_dist_set_gather_mode(sbmbp_dist_t *d, int mode);
+int sbmbp_dist_set_auto_relax(sbmbp_dist_t *d, int on);
+int sbmbp_dist_get_relaxation(const sbmbp_dist_t *d, int *field_level, int *generic_level);
 int sbmbp_dist_converge(sbmbp_dist_t *d, double crit, uint32_t max_sweeps, double damping, int *niter, double *last_maxdiff);
 int sbmbp_dist_sweep(sbmbp_dist_t *d, double damping, uint32_t n_sweeps, double *last_maxdiff);
 int sbmbp_dist_free_energy(sbmbp_dist_t *d, double *f, double *parts);

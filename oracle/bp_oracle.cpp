@@ -68,6 +68,7 @@ struct bp_t {
     bool msg_form_only = false;   // the engine was told to gather messages (sbmbp_set_gather_mode 1)
     bool auto_relax = true;       // adaptive relaxation of converge_sync
     int ar_fl = 0, ar_gl = -1;    // levels reached by the last converge_sync
+    int learn_unconverged = 0;    // BP runs of the last learning call that hit the sweep limit
     const unsigned LARGE_DEGREE = 50;  // belief_propagation.h:68
     const double EPS = 1.0e-50;        // belief_propagation.h:69
 };
@@ -508,10 +509,10 @@ double sweep_sync(bp_t &s, double damp) {
 // (2-step difference far below the 1-step difference), (W) no progress over a window of sweeps. This restates, on the CPU,
 // the state machine the engine runs on the device (kernels.h finalize_update) so that both stop on the same sweep.
 struct ar_t {
-    static constexpr int NF = 4, NG = 5, WIN = 24;
+    static constexpr int NF = 4, NG = 7, WIN = 24;
     const double FIELD[NF] = {1.0, 0.25, 0.1, 0.05};
-    const double GMIX[NG] = {0.5, 0.5, 0.25, 0.25, 0.1};
-    const double GDAMP[NG] = {1.0, 0.5, 0.5, 0.25, 0.25};
+    const double GMIX[NG] = {0.5, 0.25, 0.5, 0.25, 0.1, 0.25, 0.1};
+    const double GDAMP[NG] = {1.0, 1.0, 0.5, 0.5, 0.5, 0.25, 0.25};
     bool on = true, psi_ok = false;
     double crit = 0, base_mix = 1.0;
     int fl = 0, gl = -1;
@@ -531,14 +532,23 @@ struct ar_t {
         hold = 6; stall = 0; v1 = v2 = -1; prev_hint = 0; probing = false; armed = false;
         wn = 0; wmin = 1e300; pmin = -1; nS = 0; sigc = 0; d1p = -1; holdS = 4;
     }
-    void esc_gen() {
-        if (gl + 1 >= NG) { hold = 1 << 30; return; }
-        ++gl; reset_after();
+    int sweep = 0;            // (diagnostics only)
+    const char *why = "";
+    void trace(const char *what) const {
+        if (std::getenv("ORC_AR_TRACE")) std::fprintf(stderr, "[ar] sweep %d: %s (%s) -> field level %d, generic level %d, mix %g, damping x%g\n", sweep, what, why, fl, gl, mix(), damp());
+    }
+    void esc_gen() {  // the next level that changes anything (a field level may already have taken the mix below a level's cap)
+        const double m0 = mix(), d0 = damp();
+        while (gl + 1 < NG) {
+            ++gl;
+            if (mix() < m0 || damp() < d0) { reset_after(); trace("generic"); return; }
+        }
+        hold = 1 << 30;  // the ladder is used up: the run goes on as it is
     }
     void esc_field() {
         int nf = fl;
         while (nf + 1 < NF && !(FIELD[nf] < mix())) ++nf;   // the next cap that actually lowers the mix
-        if (FIELD[nf] < mix()) { fl = nf; reset_after(); }
+        if (FIELD[nf] < mix()) { fl = nf; reset_after(); trace("field"); }
         else esc_gen();
     }
     // after sweep `it`: v = reported difference of kind `kind`, Sraw = unrelaxed sums of the new marginals. Returns true when
@@ -555,16 +565,12 @@ struct ar_t {
             if (kind == 1 && v < crit) conv = true;
             else if (v1 >= 0) {
                 const double one = kind == 1 ? v : v1, two = kind == 1 ? v1 : v;
-                if (two < 0.5 * one) { esc_gen(); esc = true; }
+                if (two < 0.5 * one) { why = "P: probe"; esc_gen(); esc = true; }
                 else { hold = 8; stall = 0; }
             }
         } else {
             if (kind == 1) {
                 if (v < crit) conv = true;
-                else if (was_psi && prev_hint > 0) {  // first 1-step value after the hints armed the exact criterion
-                    if (prev_hint < 0.5 * v) { esc_gen(); esc = true; }
-                    else prev_hint = 0;
-                }
             } else hint(v);
             if (!conv && !esc) {
                 if (hold > 0) --hold;
@@ -574,8 +580,8 @@ struct ar_t {
                 }
                 v2 = v1; v1 = v;
                 wmin = std::min(wmin, v); ++wn;
-                if (wn >= WIN * (1 + std::max(0, gl))) {
-                    if (pmin >= 0 && wmin >= 0.9 * pmin && hold < (1 << 29)) { esc_gen(); esc = true; }
+                if (wn >= WIN * (1 + std::min(3, std::max(0, gl)))) {
+                    if (pmin >= 0 && wmin >= 0.9 * pmin && hold < (1 << 29)) { why = "W"; esc_gen(); esc = true; }
                     else { pmin = wmin; wmin = 1e300; wn = 0; }
                 }
             }
@@ -589,13 +595,13 @@ struct ar_t {
             double d1 = 0, d2 = 0, tot = 0;
             for (size_t q = 0; q < Q; ++q) { d1 = std::max(d1, std::fabs(Sraw[q] - S1[q])); d2 = std::max(d2, std::fabs(Sraw[q] - S2[q])); tot += std::fabs(Sraw[q]); }
             const bool sig = d2 < 0.5 * d1 && d1 > 1e-9 * tot;
-            if (sig && d1 > 0.05 * tot) fe = true;
-            else if (sig && (d1p < 0 || d1 >= 0.9 * d1p)) { if (++sigc >= 6) fe = true; }
+            if (sig && d1 > 0.05 * tot && fl == 0) fe = true;                                  // a violent swing: act at once
+            else if (sig && (d1p < 0 || d1 >= 0.98 * d1p)) { if (++sigc >= 6) fe = true; }  // a swing that does not die out
             else sigc = 0;
             d1p = d1;
         }
         S2 = S1; S1 = Sraw; nS = std::min(nS + 1, 2);
-        if (fe) esc_field();
+        if (fe) { why = "F"; esc_field(); }
         return false;
     }
     void hint(double v) {  // a 2-step value can only arm the exact criterion (kernels.h HINT_SCALE)
@@ -637,12 +643,15 @@ int converge_sync(bp_t &s, double crit, unsigned max_iter, double damp, double *
         double v = d1;
         if (kind == 2) {
             v = 0.0;
-            if (Mold.size() == s.M.size()) { for (size_t k = 0; k < s.M.size(); ++k) { const double x = std::fabs(s.M[k] - Mold[k]); if (x > v || x != x) v = x; } }
-            else v = d1;
+            if (Mold.size() == s.M.size()) {
+                for (size_t k = 0; k < s.M.size(); ++k) { const double x = std::fabs(s.M[k] - Mold[k]); if (x > v || x != x) v = x; }
+                v /= damp * ar.damp();  // a damped message moves by damp * (new - old) per sweep: the probe compares like with like
+            } else v = d1;
         }
         if (last_diff) *last_diff = d1;
         std::fill(Sraw.begin(), Sraw.end(), 0.0);
         for (uint32_t i = 0; i < s.N; ++i) { const double gi = gweight(s, i); for (uint32_t q = 0; q < Q; ++q) Sraw[q] += gi * s.psi[size_t(i) * Q + q]; }
+        ar.sweep = it;
         if (ar.after_sweep(v, kind, Sraw, was_psi)) { result = it; break; }
     }
     s.ar_fl = ar.fl; s.ar_gl = ar.gl;
@@ -1086,6 +1095,7 @@ void orc_bp_compute_h(void *sp) { compute_h_full(*static_cast<bp_t *>(sp)); }
 void orc_bp_set_field_mix(void *sp, double a) { static_cast<bp_t *>(sp)->field_mix = a; static_cast<bp_t *>(sp)->Sprev.clear(); }
 // the same without forgetting the previous sums (a schedule that lowers the mix in the middle of a run)
 void orc_bp_set_field_mix_keep(void *sp, double a) { static_cast<bp_t *>(sp)->field_mix = a; }
+int orc_bp_learn_unconverged(void *sp) { return static_cast<bp_t *>(sp)->learn_unconverged; }
 void orc_bp_set_auto_relax(void *sp, int on) { static_cast<bp_t *>(sp)->auto_relax = on != 0; }
 void orc_bp_set_msg_form(void *sp, int on) { static_cast<bp_t *>(sp)->msg_form_only = on != 0; }
 void orc_bp_ar_levels(void *sp, int *fl, int *gl) { *fl = static_cast<bp_t *>(sp)->ar_fl; *gl = static_cast<bp_t *>(sp)->ar_gl; }
@@ -1126,14 +1136,16 @@ int orc_bp_learning(void *sp, float learning_conv_crit, unsigned learning_max_ti
     auto &s = *static_cast<bp_t *>(sp);
     double fold = 0.0, fdiff = 1.0;
     int steps = 0;
+    s.learn_unconverged = 0;
     // the two rules of the engine's synchronous EM loop (sbmbp_set_learning_schedule defaults): field relaxation 0.3
     // inside the BP runs, and the snap tolerance min(N * crit, 0.01) of the group-size truncation
     const double keep_mix = s.field_mix;
     if (sync) { s.field_mix = std::min(s.field_mix, 0.3); s.Sprev.clear(); }
     for (unsigned t = 0; t < learning_max_time; ++t) {
         if (fdiff < learning_conv_crit) learning_conv_crit *= 0.1;
-        if (sync) converge_sync(s, learning_conv_crit, learning_max_time, dumping_rate, nullptr);
-        else converge_async(s, learning_conv_crit, learning_max_time, dumping_rate, *static_cast<rng_t *>(rng), 0);
+        const int it = sync ? converge_sync(s, learning_conv_crit, learning_max_time, dumping_rate, nullptr)
+                            : converge_async(s, learning_conv_crit, learning_max_time, dumping_rate, *static_cast<rng_t *>(rng), 0);
+        if (it < 0) ++s.learn_unconverged;
         em_expect(s);
         double fnew = free_energy(s, series_K, nullptr);
         fdiff = std::fabs(fnew - fold);

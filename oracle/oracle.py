@@ -55,6 +55,7 @@ def lib():
             "orc_bp_set_field_mix": (None, [C.c_void_p, C.c_double]),
             "orc_bp_set_field_mix_keep": (None, [C.c_void_p, C.c_double]),
             "orc_bp_set_auto_relax": (None, [C.c_void_p, C.c_int]),
+            "orc_bp_learn_unconverged": (C.c_int, [C.c_void_p]),
             "orc_bp_set_msg_form": (None, [C.c_void_p, C.c_int]),
             "orc_bp_ar_levels": (None, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
             "orc_bp_node_update": (C.c_double, [C.c_void_p, C.c_uint32, C.c_double, C.c_int]),
@@ -258,3 +259,7 @@ class OracleBP:
         steps = lib().orc_bp_learning(self._h, lcrit, tmax, lr, damp, rng._h if rng is not None else None,
                                       int(sync), series_K, C.byref(f))
         return steps, f.value
+
+    def learn_unconverged(self):
+        """BP runs inside the last learning() call that hit the sweep limit (0: every run converged)"""
+        return lib().orc_bp_learn_unconverged(self._h)

@@ -219,6 +219,16 @@ class BeliefPropagation:
         """0 = automatic (marginal-gather sweep when exact), 1 = always gather messages"""
         check(self._lib.sbmbp_set_gather_mode(self._h, mode))
 
+    def set_auto_relax(self, on=True):
+        """adaptive relaxation of converge / inference / learning (sbmbp.h); off = plain synchronous sweeps"""
+        check(self._lib.sbmbp_set_auto_relax(self._h, int(on)))
+
+    def relaxation(self):
+        """(field level, generic level, field_mix, damping factor) the last converge call ended on; (0, -1, ., 1.0): never relaxed"""
+        fl, gl, mix, dmp = C.c_int(0), C.c_int(0), C.c_double(0.0), C.c_double(0.0)
+        check(self._lib.sbmbp_get_relaxation(self._h, C.byref(fl), C.byref(gl), C.byref(mix), C.byref(dmp)))
+        return fl.value, gl.value, mix.value, dmp.value
+
     def set_learning_schedule(self, field_mix=0.3, snap=1.0):
         """field relaxation inside the EM loop's BP runs and the snap tolerance of the group-size truncation (sbmbp.h)"""
         check(self._lib.sbmbp_set_learning_schedule(self._h, field_mix, snap))

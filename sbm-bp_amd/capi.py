@@ -43,7 +43,7 @@ class DistInfo(C.Structure):
 
 class ConvState(C.Structure):
     _fields_ = [("maxdiff", C.c_double), ("conv_iter", C.c_int), ("sweep_idx", C.c_int), ("stop", C.c_int),
-                ("last_exact", C.c_int)]
+                ("last_exact", C.c_int), ("pause", C.c_int), ("ar_field_level", C.c_int), ("ar_generic_level", C.c_int)]
 
 
 class ShardDesc(C.Structure):
@@ -93,6 +93,8 @@ SYMBOLS = {
     "sbmbp_get_field": (C.c_int, [C.c_void_p, c_dp]),
     "sbmbp_set_schedule": (C.c_int, [C.c_void_p, C.c_double, C.c_uint32]),
     "sbmbp_set_gather_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "sbmbp_set_auto_relax": (C.c_int, [C.c_void_p, C.c_int]),
+    "sbmbp_get_relaxation": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), c_dp, c_dp]),
     "sbmbp_set_learning_schedule": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "sbmbp_converge": (C.c_int, [C.c_void_p, C.c_double, C.c_uint32, C.c_double, C.POINTER(C.c_int), c_dp]),
     "sbmbp_sweep": (C.c_int, [C.c_void_p, C.c_double, C.c_uint32, c_dp]),
@@ -118,6 +120,7 @@ SYMBOLS = {
     "sbmbp_shard_set_incoming": (C.c_int, [C.c_void_p, C.c_int]),
     "sbmbp_shard_state_record": (C.c_int, [C.c_void_p, C.c_int]),
     "sbmbp_shard_state_wait": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(ConvState)]),
+    "sbmbp_shard_resume": (C.c_int, [C.c_void_p]),
     "sbmbp_shard_pack": (C.c_int, [C.c_void_p, C.c_uint32, c_u32p, C.c_uint32, c_dp, C.c_uint32]),
     "sbmbp_shard_nonedge_exact_partial": (C.c_int, [C.c_void_p, c_dp, C.c_int]),
     "sbmbp_shard_set_io": (C.c_int, [C.c_void_p, c_u32p, c_u32p, c_dp, c_dp, c_dp, C.c_uint32]),
@@ -164,6 +167,8 @@ SYMBOLS = {
     "sbmbp_dist_set_schedule": (C.c_int, [_D, C.c_double, C.c_uint32]),
     "sbmbp_dist_set_learning_schedule": (C.c_int, [_D, C.c_double, C.c_double]),
     "sbmbp_dist_set_gather_mode": (C.c_int, [_D, C.c_int]),
+    "sbmbp_dist_set_auto_relax": (C.c_int, [_D, C.c_int]),
+    "sbmbp_dist_get_relaxation": (C.c_int, [_D, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sbmbp_dist_converge": (C.c_int, [_D, C.c_double, C.c_uint32, C.c_double, C.POINTER(C.c_int), c_dp]),
     "sbmbp_dist_sweep": (C.c_int, [_D, C.c_double, C.c_uint32, c_dp]),
     "sbmbp_dist_free_energy": (C.c_int, [_D, c_dp, c_dp]),

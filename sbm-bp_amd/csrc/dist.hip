@@ -791,7 +791,7 @@ int run(sbmbp_dist *d, double crit, u32 max_sweeps, double damping, int *niter, 
     CHK(sbmbp_set_schedule(d->eng, d->field_mix, 1));
     CHK(begin_run(d, crit, psi_ok, psi_ok && !first_explicit));
     u32 done = 0;
-    sbmbp_conv_state cs{0.0, -1, 0, 0, 1};
+    sbmbp_conv_state cs{0.0, -1, 0, 0, 1, 0, 0, -1};
     // batch sizes follow the decay of the reported difference (as run_sweeps of the single engine does): identical on every
     // rank, because the state they are computed from is
     const u32 batch_max = std::max<u32>(1, d->check_every);
@@ -809,17 +809,21 @@ int run(sbmbp_dist *d, double crit, u32 max_sweeps, double damping, int *niter, 
         }
         if (st.maxdiff > 0) { prev_md = st.maxdiff; prev_idx = st.sweep_idx; }
     };
+    bool form_psi = psi_ok;  // adaptive relaxation can ask for damping in the middle of a run (sbmbp_conv_state::pause): every
+                             // rank sees the same state, so all switch to the message-gather form on the same sweep
+    u32 psi_count = 0;
     auto queue_batch = [&](int slot) -> int {
         const u32 batch = std::min(next_batch, max_sweeps - done);
         for (u32 b = 0; b < batch; ++b) {
             const u32 j = done + b;
-            if (psi_ok && !(j == 0 && first_explicit)) CHK(queue_sweep_psi(d, j));
-            else CHK(queue_sweep_explicit(d, j, damping, psi_ok));
+            if (form_psi && !(j == 0 && first_explicit)) CHK(queue_sweep_psi(d, j));
+            else CHK(queue_sweep_explicit(d, j, damping, form_psi));
         }
         done += batch;
         return sbmbp_shard_state_record(d->eng, slot);
     };
-    if (max_sweeps > 0) {
+    while (done < max_sweeps) {
+        const u32 start = done;
         CHK(queue_batch(0));
         for (int k = 0;; ++k) {
             const bool more = done < max_sweeps;
@@ -831,6 +835,13 @@ int run(sbmbp_dist *d, double crit, u32 max_sweeps, double damping, int *niter, 
                 break;
             }
         }
+        if (form_psi) psi_count += u32(cs.sweep_idx) - start - ((first_explicit && start == 0 && cs.sweep_idx > 0) ? 1 : 0);
+        if (!(cs.stop && cs.pause)) break;
+        done = u32(cs.sweep_idx);
+        form_psi = false;
+        CHK(sbmbp_shard_resume(d->eng));
+        next_batch = batch_max;
+        prev_md = -1.0;
     }
     HIPCHK(hipStreamSynchronize(d->s_comm));
     for (auto sx : d->s_aux) HIPCHK(hipStreamSynchronize(sx));
@@ -843,9 +854,9 @@ int run(sbmbp_dist *d, double crit, u32 max_sweeps, double damping, int *niter, 
     double exact = cs.maxdiff;
     if (executed > 0 && last != nullptr && !cs.last_exact) CHK(exact_diff(d, &exact));
     d->total_sweeps += executed;
-    if (psi_ok) d->psi_sweeps += executed - ((first_explicit && executed > 0) ? 1 : 0);
+    d->psi_sweeps += psi_count;
     if (executed > 0)
-        d->consistent = damping == 1.0 && sbmbp_shard_query(d->eng, 0) == 1 && sbmbp_shard_query(d->eng, 1) == 0;
+        d->consistent = damping == 1.0 && cs.ar_generic_level < 2 /* levels 0 and 1 leave the damping at 1 */ && sbmbp_shard_query(d->eng, 0) == 1 && sbmbp_shard_query(d->eng, 1) == 0;
     if (niter) *niter = cs.conv_iter;
     if (last) *last = exact;
     return SBMBP_OK;
@@ -1232,6 +1243,15 @@ int sbmbp_dist_set_gather_mode(sbmbp_dist_t *d, int mode) {
     if (!d || mode < 0 || mode > 1) return SBMBP_ERR_ARG;
     d->gather_mode = mode;
     return SBMBP_OK;
+}
+
+int sbmbp_dist_set_auto_relax(sbmbp_dist_t *d, int on) {
+    if (!d) return SBMBP_ERR_ARG;
+    return sbmbp_set_auto_relax(d->eng, on);
+}
+int sbmbp_dist_get_relaxation(const sbmbp_dist_t *d, int *field_level, int *generic_level) {
+    if (!d) return SBMBP_ERR_ARG;
+    return sbmbp_get_relaxation(d->eng, field_level, generic_level, nullptr, nullptr);
 }
 
 int sbmbp_dist_converge(sbmbp_dist_t *d, double crit, uint32_t max_sweeps, double damping, int *niter, double *last) {

@@ -102,6 +102,8 @@ struct sbmbp_engine {
     int gather_mode = 0;         // 0 = automatic, 1 = always gather messages (explicit form)
     uint64_t psi_sweeps = 0;     // sweeps executed by k_sweep_psi
     double field_mix = 1.0;
+    bool auto_relax = true;      // adaptive relaxation of converge (sbmbp_set_auto_relax; kernels.h dev_params::ar_*)
+    int ar_fl = 0, ar_gl = -1;   // levels the last converge call ended on
     double learn_field_mix = 0.3, learn_snap = 1.0;  // sbmbp_set_learning_schedule
     uint32_t check_every = 1;
     int nonedge_mode = 0, series_order = 0;
@@ -217,6 +219,14 @@ int upload_params(sbmbp_engine *e, double crit, bool hinted = false) {
     P.hinted = hinted ? 1 : 0;  // the sweeps of this run report 2-step hints until k_finalize arms the exact criterion
     P.exact = 0;
     P.last_exact = 1;
+    P.pause = 0;
+    P.ar_on = (e->auto_relax && crit >= 0) ? 1 : 0;  // fixed sweep counts (crit < 0) are plain Jacobi sweeps
+    P.ar_psi_ok = hinted ? 1 : 0;
+    P.ar_gl = -1;
+    P.ar_base_mix = e->field_mix;
+    P.damp_auto = 1.0;
+    P.ar_v1 = P.ar_v2 = P.ar_pmin = P.ar_d1p = -1.0;
+    P.ar_wmin = 1e300;
     HIPCHK(hipMemcpyAsync(e->d_P, &P, sizeof P, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));  // P is a stack object
     return SBMBP_OK;
@@ -371,7 +381,8 @@ int collect_timing(sbmbp_engine *e) {
     return SBMBP_OK;
 }
 
-struct conv_state { double maxdiff; int conv_iter, sweep_idx, stop, have_prev, hinted, exact, last_exact; };
+struct conv_state { double maxdiff; int conv_iter, sweep_idx, stop, have_prev, hinted, exact, last_exact, pause, ar_fl, ar_gl; };
+static_assert(offsetof(dev_params, ar_gl) - offsetof(dev_params, maxdiff) == offsetof(conv_state, ar_gl), "conv_state mirrors dev_params from maxdiff on");
 
 int read_conv_state(sbmbp_engine *e, conv_state *cs) {
     HIPCHK(hipMemcpyAsync(cs, reinterpret_cast<const char *>(e->d_P) + offsetof(dev_params, maxdiff), sizeof(conv_state),
@@ -411,7 +422,7 @@ int run_sweeps(sbmbp_engine *e, double crit, uint32_t max_sweeps, double damping
     CHK(launch_field(e, 1));
     CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (e->Q + 1)));
     uint32_t done = 0;
-    conv_state cs{0.0, -1, 0, 0, 0, 0, 0, 1};
+    conv_state cs{0.0, -1, 0, 0, 0, 0, 0, 1, 0, 0, -1};
     const uint32_t batch_max = std::max<uint32_t>(1, e->check_every);
     // the first sweep after a state or parameter change gathers the messages themselves (explicit form), unless the
     // state is the device initialisation "message = sender's marginal", which the marginal-gather form starts from
@@ -441,11 +452,13 @@ int run_sweeps(sbmbp_engine *e, double crit, uint32_t max_sweeps, double damping
         }
         if (st.maxdiff > 0) { prev_md = st.maxdiff; prev_idx = st.sweep_idx; }
     };
+    bool form_psi = psi_ok;  // adaptive relaxation can ask for damping in the middle of a run: the rest runs in the message-gather form
+    uint32_t psi_count = 0;
     auto queue_batch = [&](int slot) -> int {
         const uint32_t batch = std::min(next_batch, max_sweeps - done);
         for (uint32_t b = 0; b < batch; ++b) {
             const uint32_t j = done + b;
-            const bool pf = psi_ok && !(j == 0 && first_explicit);
+            const bool pf = form_psi && !(j == 0 && first_explicit);
             CHK(launch_sweep(e, j, damping, pf, pf && j == 0 && first_from_psi));
         }
         done += batch;
@@ -454,7 +467,8 @@ int run_sweeps(sbmbp_engine *e, double crit, uint32_t max_sweeps, double damping
         HIPCHK(hipEventRecord(e->ev_cs[slot], e->stream));
         return SBMBP_OK;
     };
-    if (max_sweeps > 0) {
+    while (done < max_sweeps) {
+        const uint32_t start = done;
         CHK(queue_batch(0));
         for (int k = 0;; ++k) {
             const bool more = done < max_sweeps;
@@ -470,6 +484,15 @@ int run_sweeps(sbmbp_engine *e, double crit, uint32_t max_sweeps, double damping
                 break;
             }
         }
+        if (form_psi) psi_count += uint32_t(cs.sweep_idx) - start - ((first_explicit && start == 0 && cs.sweep_idx > 0) ? 1 : 0);
+        if (!(cs.stop && cs.pause)) break;
+        // the device asked for damped sweeps (dev_params::pause): what was queued behind that sweep did not run
+        done = uint32_t(cs.sweep_idx);
+        form_psi = false;
+        hipLaunchKernelGGL(k_resume, dim3(1), dim3(64), 0, e->stream, e->d_P);
+        HIPCHK(hipGetLastError());
+        next_batch = batch_max;
+        prev_md = -1.0;
     }
     if (e->timing) CHK(collect_timing(e));
     const uint32_t executed = uint32_t(cs.sweep_idx);
@@ -479,12 +502,16 @@ int run_sweeps(sbmbp_engine *e, double crit, uint32_t max_sweeps, double damping
     // the last executed sweep reported a 2-step hint: measure the reference's 1-step difference when the caller wants it
     if (executed > 0 && last != nullptr && !cs.last_exact) CHK(message_diff(e, &exact));
     e->sweeps += executed;
-    if (psi_ok) e->psi_sweeps += executed - ((first_explicit && executed > 0) ? 1 : 0);
+    e->psi_sweeps += psi_count;
+    const bool relaxed = cs.ar_fl > 0 || cs.ar_gl >= 0;
+    const double damp_eff = damping * ar_gen_damp(cs.ar_gl);
     if (executed > 0) {
-        e->psi_consistent = (damping == 1.0 && (!e->has_clamp || e->clamp_onehot) && e->w_positive);
+        e->psi_consistent = (damp_eff == 1.0 && (!e->has_clamp || e->clamp_onehot) && e->w_positive);
         e->init_from_psi = false;
     }
-    e->field_fresh = (e->field_mix >= 1.0) && executed > 0;
+    e->field_fresh = (e->field_mix >= 1.0) && !relaxed && executed > 0;
+    e->ar_fl = cs.ar_fl;
+    e->ar_gl = cs.ar_gl;
     if (niter) *niter = cs.conv_iter;
     if (last) *last = exact;
     return SBMBP_OK;
@@ -1241,6 +1268,20 @@ int sbmbp_set_learning_schedule(sbmbp_engine_t *e, double field_mix, double snap
     return SBMBP_OK;
 }
 
+int sbmbp_set_auto_relax(sbmbp_engine_t *e, int on) {
+    if (!e) return SBMBP_ERR_ARG;
+    e->auto_relax = on != 0;
+    return SBMBP_OK;
+}
+int sbmbp_get_relaxation(const sbmbp_engine_t *e, int *field_level, int *generic_level, double *field_mix, double *damping_factor) {
+    if (!e) return SBMBP_ERR_ARG;
+    if (field_level) *field_level = e->ar_fl;
+    if (generic_level) *generic_level = e->ar_gl;
+    if (field_mix) *field_mix = std::min(std::min(e->field_mix, ar_field_cap(e->ar_fl)), ar_gen_mix(e->ar_gl));
+    if (damping_factor) *damping_factor = ar_gen_damp(e->ar_gl);
+    return SBMBP_OK;
+}
+
 int sbmbp_set_gather_mode(sbmbp_engine_t *e, int mode) {
     device_scope dev_(e);
     if (!e || mode < 0 || mode > 1) return SBMBP_ERR_ARG;
@@ -1672,6 +1713,19 @@ int sbmbp_shard_state_wait(sbmbp_engine_t *e, int slot, sbmbp_conv_state *out) {
     out->sweep_idx = cs.sweep_idx;
     out->stop = cs.stop;
     out->last_exact = cs.last_exact;
+    out->pause = cs.pause;
+    out->ar_field_level = cs.ar_fl;
+    out->ar_generic_level = cs.ar_gl;
+    return SBMBP_OK;
+}
+
+// the host's answer to a pause (adaptive relaxation asked for damping in the middle of a marginal-gather run): the queued
+// sweeps behind it were skipped; the run goes on in the message-gather form
+int sbmbp_shard_resume(sbmbp_engine_t *e) {
+    device_scope dev_(e);
+    IS_SHARD(e);
+    hipLaunchKernelGGL(k_resume, dim3(1), dim3(64), 0, e->stream, e->d_P);
+    HIPCHK(hipGetLastError());
     return SBMBP_OK;
 }
 
@@ -1869,6 +1923,11 @@ int sbmbp_shard_poll(sbmbp_engine_t *e, sbmbp_conv_state *out) {
     out->sweep_idx = cs.sweep_idx;
     out->stop = cs.stop;
     out->last_exact = cs.last_exact;
+    out->pause = cs.pause;
+    out->ar_field_level = cs.ar_fl;
+    out->ar_generic_level = cs.ar_gl;
+    e->ar_fl = cs.ar_fl;
+    e->ar_gl = cs.ar_gl;
     return SBMBP_OK;
 }
 

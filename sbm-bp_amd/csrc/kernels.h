@@ -44,9 +44,28 @@ struct dev_params {
     // HINT_SCALE * crit, k_finalize sets exact = 1 and from the next sweep on the kernels read the other message buffer
     // too and report the reference's 1-step difference (bp.cpp:1059-1063), on which the stop flag then works.
     int hinted;
-    int exact;
+    int exact;                 // EFFECTIVE flag of the next marginal-gather sweep: report the 1-step difference (armed XOR probing)
     int last_exact;            // maxdiff of the last executed sweep is a 1-step difference (not a hint)
-    int pad_;
+    int pause;                 // with stop: the run must continue in the message-gather form (adaptive relaxation asked for damping)
+    // ---- adaptive relaxation (CPU twin: oracle/bp_oracle.cpp ar_t). Plain Jacobi sweeps can oscillate where
+    // the reference's random-sequential sweep converges (it keeps h_ current inside a sweep, bp.cpp:1088-1095, and never
+    // updates two neighbours at once). finalize_update watches three signatures and relaxes the schedule when one shows; the
+    // fixed points do not move: (F) the raw field sums swing with period 2 -> lower field_mix; (P) the messages swing with
+    // period 2 (2-step difference far below the 1-step difference: checked by ONE probe sweep of the other kind after four
+    // sweeps without progress) or (W) a whole window of sweeps brought no progress -> next level of (field_mix, damping).
+    int ar_fl, ar_gl;          // field level (caps 1, 0.25, 0.1, 0.05), generic level (-1 = none; (mix cap, damping) ladder)
+    int ar_on;                 // host: enabled for this run (converge calls; never for fixed sweep counts)
+    int ar_psi_ok;             // host: the run is in the marginal-gather form as long as damping stays 1
+    int ar_armed;              // the hints have armed the exact criterion
+    int ar_probing;            // the next sweep reports the OTHER kind of difference
+    int ar_probe2;             // message-gather sweeps: report the 2-step difference (k_sweep reads the slot it overwrites)
+    int ar_stall, ar_hold, ar_holdS, ar_sigc, ar_nS, ar_wn, ar_pad;
+    double ar_base_mix;        // the caller's field_mix
+    double damp_auto;          // factor on the caller's damping (message-gather sweeps)
+    double ar_v1, ar_v2;       // reported differences of the last two regular sweeps (-1: none)
+    double ar_wmin, ar_pmin;   // window minimum so far, minimum of the window before (-1: none)
+    double ar_d1p;             // last swing of the field sums (-1: none)
+    double ar_S1[QMAX], ar_S2[QMAX];  // raw field sums of the last two sweeps
     // Degree-corrected field factor of the rows of up to FT_D edges: ftab[d][q] = eta[q] exp(-d (h[q] - min h)/N), rewritten with h
     // by every finalize launch. A row then loads its Q factors (issued before its product loop) instead of evaluating Q
     // exponentials (4 % of the sweep at Q = 8, dc 1); the entries are the very expression apply_field evaluates, bit for bit.
@@ -670,6 +689,8 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
 
     // ---- phase 3: lane per directed edge: cavity, normalise, damp, store
     double md = 0.0;
+    const int probe2 = P->ar_probe2;  // adaptive relaxation's probe sweep: report |m^{t+1} - m^{t-1}| (m^{t-1} sits in the slot written below)
+    damp *= P->damp_auto;
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
         const int le = j * frame_cfg<Q>::TPB + tid;
@@ -706,11 +727,20 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
                     tot = apply_field_x<Q>(P, dc, di, cav, ce);
                 }
                 const double inv = 1.0 / tot;
+                double ref[Q];
+                if (probe2) {  // uniform
+                    load_msg<Q>(Mnew, size_t(e0 + le), ref);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) ref[q] = mo[j][q];
+                }
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
                     const double nv = cav[q] * inv;
-                    md = nanmax(md, fabs(mo[j][q] - nv));
                     out[q] = damp * nv + (1.0 - damp) * mo[j][q];
+                    // 1-step: against the undamped value (bp.cpp:1059-1063); the probe compares what is stored, and a damped
+                    // message moves by damp * (new - old) per sweep, so it is scaled back to compare like with like
+                    md = nanmax(md, probe2 ? fabs(ref[q] - out[q]) / damp : fabs(ref[q] - nv));
                 }
             }
             store_msg_stream<Q>(Mnew, size_t(e0 + le), out);
@@ -742,6 +772,15 @@ k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, 
 // Everything is loaded before anything is stored (P may alias nothing else here, but the compiler cannot know that the
 // stores to P do not change what the later loads from P return): one memory round trip instead of a chain of them. With a
 // run-time Q and local arrays indexed by it the same code lived in scratch memory and took 6 (Q = 2) to 21 us (Q = 8).
+// ladders of the adaptive relaxation (dev_params::ar_*; the same numbers as oracle/bp_oracle.cpp ar_t)
+// field caps 1, 0.25, 0.1, 0.05; generic levels (mix cap, damping factor): (0.5,1) (0.25,1) (0.5,0.5) (0.25,0.5) (0.1,0.5) (0.25,0.25) (0.1,0.25)
+constexpr int AR_NF = 4, AR_NG = 7, AR_WIN = 24;
+__host__ __device__ __forceinline__ double ar_field_cap(int fl) { return fl <= 0 ? 1.0 : (fl == 1 ? 0.25 : (fl == 2 ? 0.1 : 0.05)); }
+__host__ __device__ __forceinline__ double ar_gen_mix(int gl) {
+    return gl < 0 ? 1.0 : (gl == 0 || gl == 2) ? 0.5 : (gl == 1 || gl == 3 || gl == 5) ? 0.25 : 0.1;
+}
+__host__ __device__ __forceinline__ double ar_gen_damp(int gl) { return gl <= 1 ? 1.0 : (gl <= 4 ? 0.5 : 0.25); }
+
 template <int Q>
 __device__ __forceinline__ void finalize_update(dev_params *__restrict__ P, const double *sums /* [Q] then the max */, int mode,
                                                 double *__restrict__ diff_hist, uint32_t hist_cap, int md_exact, double *s_hN /* LDS [Q]: h/N for field_table */) {
@@ -750,13 +789,130 @@ __device__ __forceinline__ void finalize_update(dev_params *__restrict__ P, cons
     for (int a = 0; a < Q * Q; ++a) cab[a] = P->cab[a];
 #pragma unroll
     for (int q = 0; q < Q; ++q) { eta[q] = P->eta[q]; Sold[q] = P->S[q]; }
-    const double mix = P->field_mix, invN = P->invN, beta = P->beta, crit = P->crit, prev_hint = P->prev_hint;
+    const double invN = P->invN, beta = P->beta, crit = P->crit;
+    double mix = P->field_mix, prev_hint = P->prev_hint;
     const int have_prev = P->have_prev, hinted = P->hinted, exact = P->exact, conv_iter = P->conv_iter, it = P->sweep_idx;
+    // adaptive relaxation: the whole state is loaded up front as well (one round trip)
+    const int ar_on = P->ar_on, psi_ok = P->ar_psi_ok, probe2 = P->ar_probe2;
+    int fl = P->ar_fl, gl = P->ar_gl, armed = P->ar_armed, probing = P->ar_probing, stall = P->ar_stall, hold = P->ar_hold,
+        holdS = P->ar_holdS, sigc = P->ar_sigc, nS = P->ar_nS, wn = P->ar_wn;
+    const double base_mix = P->ar_base_mix;
+    double v1 = P->ar_v1, v2 = P->ar_v2, wmin = P->ar_wmin, pmin = P->ar_pmin, d1p = P->ar_d1p;
+    double S1[Q], S2[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { S1[q] = P->ar_S1[q]; S2[q] = P->ar_S2[q]; }
+
+    if (mode == 0) {
+        const double md = sums[Q];
+        // what the sweep reported: 1 = the reference's 1-step difference (bp.cpp:1059-1063), 2 = a 2-step difference
+        const int kind = md_exact ? (probe2 ? 2 : 1) : ((hinted && !exact) ? 2 : 1);
+        bool conv = false, esc = false;
+        auto reset_after = [&]() {
+            hold = 6; stall = 0; v1 = v2 = -1.0; prev_hint = 0.0; probing = 0; armed = 0;
+            wn = 0; wmin = 1e300; pmin = -1.0; nS = 0; sigc = 0; d1p = -1.0; holdS = 4;
+        };
+        auto cur_mix = [&]() { return fmin(fmin(base_mix, ar_field_cap(fl)), ar_gen_mix(gl)); };
+        auto esc_gen = [&]() {  // the next level that changes anything (a field level may already have the mix below a level's cap)
+            const double m0 = cur_mix(), d0 = ar_gen_damp(gl);
+            while (gl + 1 < AR_NG) {
+                ++gl;
+                if (cur_mix() < m0 || ar_gen_damp(gl) < d0) { reset_after(); return; }
+            }
+            hold = 1 << 30;  // the ladder is used up: the run goes on as it is
+        };
+        auto esc_field = [&]() {
+            int nf = fl;
+            while (nf + 1 < AR_NF && !(ar_field_cap(nf) < cur_mix())) ++nf;  // the next cap that actually lowers the mix
+            if (ar_field_cap(nf) < cur_mix()) { fl = nf; reset_after(); }
+            else esc_gen();
+        };
+        auto hint = [&](double v) {  // a 2-step value can only arm the exact criterion
+            double scale = HINT_SCALE;
+            if (prev_hint > 0.0 && v > 0.0 && v < prev_hint) {
+                const double r = v / prev_hint;
+                scale = fmin(HINT_SCALE_MAX, fmax(HINT_SCALE, 1.5 * (1.0 + 1.0 / r) / r));
+            }
+            prev_hint = v;
+            if (v < scale * crit) armed = 1;
+        };
+        if (!ar_on) {
+            if (kind == 1) conv = md < crit; else hint(md);
+        } else if (probing) {  // (P) the probe's answer
+            probing = 0;
+            if (kind == 1 && md < crit) conv = true;
+            else if (v1 >= 0.0) {
+                const double one = kind == 1 ? md : v1, two = kind == 1 ? v1 : md;
+                if (two < 0.5 * one) { esc_gen(); esc = true; }
+                else { hold = 8; stall = 0; }
+            }
+        } else {
+            if (kind == 1) {
+                if (md < crit) conv = true;
+            } else hint(md);
+            if (!conv && !esc) {
+                if (hold > 0) --hold;
+                else {
+                    if (v2 >= 0.0 && md >= 0.98 * v2) ++stall; else stall = 0;
+                    if (stall >= 4) { probing = 1; stall = 0; }
+                }
+                v2 = v1; v1 = md;
+                wmin = fmin(wmin, md); ++wn;
+                if (wn >= AR_WIN * (1 + (gl > 0 ? (gl < 3 ? gl : 3) : 0))) {  // (W)
+                    if (pmin >= 0.0 && wmin >= 0.9 * pmin && hold < (1 << 29)) { esc_gen(); esc = true; }
+                    else { pmin = wmin; wmin = 1e300; wn = 0; }
+                }
+            }
+        }
+        if (ar_on && !conv && !esc) {  // (F) period 2 in the raw field sums
+            bool fe = false;
+            if (holdS > 0) --holdS;
+            else if (nS >= 2) {
+                double d1 = 0.0, d2 = 0.0, tot = 0.0;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) { d1 = fmax(d1, fabs(sums[q] - S1[q])); d2 = fmax(d2, fabs(sums[q] - S2[q])); tot += fabs(sums[q]); }
+                const bool sig = d2 < 0.5 * d1 && d1 > 1e-9 * tot;
+                if (sig && d1 > 0.05 * tot && fl == 0) fe = true;                              // a violent swing: act at once
+                else if (sig && (d1p < 0.0 || d1 >= 0.98 * d1p)) { if (++sigc >= 6) fe = true; }  // a swing that does not die out
+                else sigc = 0;
+                d1p = d1;
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { S2[q] = S1[q]; S1[q] = sums[q]; }
+            nS = nS < 2 ? nS + 1 : 2;
+            if (fe) esc_field();
+        }
+        mix = ar_on ? cur_mix() : mix;
+        const double dampA = ar_gen_damp(gl);
+        const bool psi_next = psi_ok && dampA == 1.0;
+        int k_next = (!psi_next || armed) ? 1 : 2;
+        if (probing) k_next = 3 - k_next;
+        P->maxdiff = md;
+        if (diff_hist != nullptr && uint32_t(it) < hist_cap) diff_hist[it] = md;
+        P->last_exact = kind == 1 ? 1 : 0;
+        P->prev_hint = prev_hint;
+        P->exact = k_next == 1 ? 1 : 0;
+        P->ar_probe2 = (!psi_next && k_next == 2) ? 1 : 0;
+        P->field_mix = mix;
+        P->damp_auto = dampA;
+        P->ar_fl = fl; P->ar_gl = gl; P->ar_armed = armed; P->ar_probing = probing; P->ar_stall = stall; P->ar_hold = hold;
+        P->ar_holdS = holdS; P->ar_sigc = sigc; P->ar_nS = nS; P->ar_wn = wn;
+        P->ar_v1 = v1; P->ar_v2 = v2; P->ar_wmin = wmin; P->ar_pmin = pmin; P->ar_d1p = d1p;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { P->ar_S1[q] = S1[q]; P->ar_S2[q] = S2[q]; }
+        if (conv && conv_iter < 0) {
+            P->conv_iter = it;
+            P->stop = 1;
+        } else if (psi_ok && dampA < 1.0 && !md_exact) {  // damping needs the message-gather form: the host switches (run_sweeps)
+            P->pause = 1;
+            P->stop = 1;
+        }
+        P->sweep_idx = it + 1;
+    }
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        double s = sums[q];
-        if (mode == 0 && have_prev && mix < 1.0) s = (1.0 - mix) * Sold[q] + mix * s;
-        S[q] = s;
+        double sv = sums[q];
+        if (mode == 0 && have_prev && mix < 1.0) sv = (1.0 - mix) * Sold[q] + mix * sv;
+        S[q] = sv;
     }
     double hN[Q], etaF[Q];
 #pragma unroll
@@ -770,26 +926,11 @@ __device__ __forceinline__ void finalize_update(dev_params *__restrict__ P, cons
 #pragma unroll
     for (int q = 0; q < Q; ++q) { P->S[q] = S[q]; P->hN[q] = hN[q]; P->etaF[q] = etaF[q]; s_hN[q] = hN[q]; }
     P->have_prev = 1;
-    if (mode == 0) {
-        const double md = sums[Q];
-        P->maxdiff = md;
-        if (diff_hist != nullptr && uint32_t(it) < hist_cap) diff_hist[it] = md;
-        const bool is_hint = hinted && !exact && !md_exact;
-        P->last_exact = is_hint ? 0 : 1;
-        if (is_hint) {  // a 2-step hint: it can only arm the exact criterion
-            double scale = HINT_SCALE;
-            if (prev_hint > 0.0 && md > 0.0 && md < prev_hint) {
-                const double r = md / prev_hint;
-                scale = fmin(HINT_SCALE_MAX, fmax(HINT_SCALE, 1.5 * (1.0 + 1.0 / r) / r));
-            }
-            P->prev_hint = md;
-            if (md < scale * crit) P->exact = 1;
-        } else if (md < crit && conv_iter < 0) {
-            P->conv_iter = it;
-            P->stop = 1;
-        }
-        P->sweep_idx = it + 1;
-    }
+}
+
+// the host's answer to dev_params::pause: the run goes on in the message-gather form (1-step differences every sweep)
+__global__ void k_resume(dev_params *__restrict__ P) {
+    if (threadIdx.x == 0) { P->stop = 0; P->pause = 0; P->hinted = 0; P->ar_psi_ok = 0; }
 }
 
 // the whole workgroup, after finalize_update and a barrier: P->ftab from the new h (dev_params)
@@ -1407,10 +1548,18 @@ k_hub_frag_cavity_msg(const uint32_t *__restrict__ row_ptr, const double *__rest
         store_vec<Q>(psi + size_t(i) * Q, pv);
     }
     double md = 0.0;
+    const int probe2 = P->ar_probe2;  // as in k_sweep
+    damp *= P->damp_auto;
     if (le < d) {
-        double b[Q], mo[Q], out[Q], cav[Q];
+        double b[Q], mo[Q], out[Q], cav[Q], ref[Q];
         load_vec<Q>(hf.b + (size_t(f) * BLOCK + tid) * Q, b);
         load_msg<Q>(Mold, size_t(e0 + le), mo);
+        if (probe2) {  // uniform
+            load_msg<Q>(Mnew, size_t(e0 + le), ref);
+        } else {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) ref[q] = mo[q];
+        }
         double ct = 0.0;
 #pragma unroll
         for (int q = 0; q < Q; ++q) { cav[q] = (b[q] > 0.0) ? A[q] / b[q] : 0.0; ct += cav[q]; }
@@ -1418,8 +1567,8 @@ k_hub_frag_cavity_msg(const uint32_t *__restrict__ row_ptr, const double *__rest
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const double nv = cav[q] * ci;
-            md = nanmax(md, fabs(mo[q] - nv));
             out[q] = damp * nv + (1.0 - damp) * mo[q];
+            md = nanmax(md, probe2 ? fabs(ref[q] - out[q]) / damp : fabs(ref[q] - nv));
         }
         store_msg<Q>(Mnew, size_t(e0 + le), out);
     }

@@ -212,6 +212,14 @@ class ShardedBP:
     def set_gather_mode(self, mode=0):
         check(self._lib.sbmbp_dist_set_gather_mode(self._h, mode))
 
+    def set_auto_relax(self, on=True):
+        check(self._lib.sbmbp_dist_set_auto_relax(self._h, int(on)))
+
+    def relaxation(self):
+        fl, gl = C.c_int(0), C.c_int(0)
+        check(self._lib.sbmbp_dist_get_relaxation(self._h, C.byref(fl), C.byref(gl)))
+        return fl.value, gl.value
+
     # -- hot path ---------------------------------------------------------------------------------
     def sweep(self, n_sweeps=1, dumping_rate=1.0, want_diff=True):
         if not want_diff:
@@ -363,6 +371,12 @@ class LocalShards:
 
     def set_gather_mode(self, mode=0):
         self._all(lambda sh: sh.set_gather_mode(mode))
+
+    def set_auto_relax(self, on=True):
+        self._all(lambda sh: sh.set_auto_relax(on))
+
+    def relaxation(self):
+        return self._all(lambda sh: sh.relaxation())[0]
 
     def sweep(self, n_sweeps=1, dumping_rate=1.0, want_diff=True):
         return self._all(lambda sh: sh.sweep(n_sweeps, dumping_rate, want_diff))[0]

@@ -130,19 +130,45 @@ def test_random_instance_against_the_oracle(S, orc, seed):
     assert _close(na1, na2, 1e-9) and _close(nna1, nna2, 1e-9)
     assert _close(cab1, cab2, 1e-8), (cab1, cab2)
     assert abs(bp.compute_overlap() - ob.overlap()) < 1e-11
-    # run on to convergence: the engine's batched driver (2-step hint, exact check, device-side stop flag) must stop
-    # where the oracle's plain loop does
+    # run on to convergence: the engine's batched driver (2-step hint, exact check, device-side stop flag, adaptive
+    # relaxation) must stop where the oracle's synchronous twin does
     it1, last1 = bp.converge(1e-9, 400, 1.0)
     it2, last2 = ob.converge_sync(1e-9, 400, 1.0)
+    relaxed = bp.relaxation()[:2] != (0, -1) or ob.ar_levels() != (0, -1)
     if np.isnan(ob.get_state()[1]).any():  # turned contradictory on the way (see above): the engine reports NaN, never convergence
         assert it1 < 0 and np.isnan(last1) and np.isnan(bp.get_state()[1]).any()
-    elif it1 >= 0 and it2 >= 0:
+        return
+    if it1 >= 0 and it2 >= 0 and not relaxed:
         # the engine checks the exact criterion only once its 2-step hint is within 8 x crit: where the differences do
         # not fall monotonically it can pass the first crossing by a few sweeps (never stop early)
         assert it2 - 1 <= it1 <= it2 + 8 and last1 < 1e-9, (it1, it2, last1)
         assert np.abs(bp.get_state()[0] - ob.get_state()[0]).max() < 1e-7
-    else:
+    elif not relaxed:
         assert (it1 < 0) == (it2 < 0) or min(last1, last2) < 4e-9, (it1, it2, last1, last2)
+    else:
+        # a relaxed run: engine and twin take their decisions from sums folded in different orders, so a threshold can fall on
+        # different sweeps; what must hold is that both end the same way, on the same levels unless a decision was a tie
+        assert (it1 < 0) == (it2 < 0) or min(last1, last2) < 1e-7, (it1, it2, last1, last2, bp.relaxation(), ob.ar_levels())
+    # "the reference converges => the engine converges": the reference's own random-sequential schedule from the same initial
+    # state (oracle's asynchronous loop = the compiled reference bit for bit on the fixtures), undamped, 400 sweeps
+    oa = orc.OracleBP(og, Q, dc)
+    oa.init_messages(t["flag"], t["conf"], t["tc"], orc.Rng(t["seed"]))
+    oa.set_params(t["cab"], t["na"], t["beta"])
+    if oa.converge_async(1e-9, 400, 1.0, orc.Rng(t["seed"] + 1), True) >= 0:
+        if it1 < 0:  # not within the first 400 sweeps (and 4 warm-up sweeps, two of them damped): a fresh run with a budget
+            bp = S.bp_conditional()
+            bp.init_messages(S.blockmodel_t(g, Q, dc), t["flag"], t["conf"], t["tc"], t["seed"])
+            bp.set_beta(t["beta"])
+            bp.expand_bp_params(S.bp_blockmodel_state(t["cab"], t["na"]))
+            it1, last1 = bp.converge(1e-9, 4000, 1.0)
+        assert it1 >= 0 and last1 < 1e-9, ("the reference converges here, the engine does not", it1, last1, bp.relaxation())
+    if it1 >= 0:  # where the engine stops is a fixed point of the plain update, relaxed schedule or not
+        psi, msg = bp.get_state()
+        chk = orc.OracleBP(og, Q, dc)
+        chk.init_messages(t["flag"], t["conf"], t["tc"], orc.Rng(t["seed"]))
+        chk.set_params(t["cab"], t["na"], t["beta"])
+        chk.set_state(psi, msg)
+        assert chk.sweep_sync(1.0) < 1e-7
 
 
 @pytest.mark.parametrize("seed", _seeds("SBMBP_FUZZ_SHARD_SEEDS", (200, 30)))
@@ -155,8 +181,11 @@ def test_random_instance_sharded_against_the_single_engine(S, seed):
     rng = np.random.default_rng(seed)
     Q, N, dc = t["Q"], t["N"], t["dc"]
     world = int(rng.integers(2, 6))
-    if N < world:
-        pytest.skip("fewer vertices than ranks")
+    redraw = 0
+    while N < world:  # fewer vertices than ranks: take the next instance of the family instead of skipping the case
+        redraw += 1
+        t = _instance(seed + 10007 * redraw)
+        Q, N, dc = t["Q"], t["N"], t["dc"]
     g = S.Graph.from_edges(t["pairs"], N)
     bp = S.bp_conditional()
     bp.init_messages(S.blockmodel_t(g, Q, dc), t["flag"], t["conf"], t["tc"], t["seed"])
@@ -190,93 +219,89 @@ def test_random_instance_sharded_against_the_single_engine(S, seed):
     sb.close()
 
 
+def _learn_instance(orc, seed, family):
+    """a random planted instance for the EM tests on which every BP run of the oracle's synchronous EM loop converges. Where a
+    BP run hits the sweep limit the EM run is a chaotic trajectory - last-bit differences in the arithmetic grow by many orders
+    of magnitude over tens of EM steps (measured: 1e-16 -> 1e-7 within six steps, tools/trace_learn_instance.py) - and
+    step-for-step agreement means nothing; such draws are replaced by the next draw of the family BEFORE anything is compared
+    (never after a mismatch)."""
+    from sbm_bp_amd import synth
+    for redraw in range(50):
+        s = seed + 10007 * redraw
+        if family == "single":
+            rng = np.random.default_rng(7000 + s)
+            Q = int(rng.choice([2, 3, 4, 6]))
+            N = int(rng.choice([120, 300, 600])) // Q * Q
+            c = float(rng.choice([4.0, 7.0, 10.0]))
+            eps = float(rng.choice([0.05, 0.15, 0.3]))
+            pairs, cin, cout = synth.planted_partition(N, Q, c, eps, 100 + s)
+            cab0 = synth.cab_matrix(Q, cin * rng.uniform(0.7, 1.3), cout * rng.uniform(0.7, 1.6))
+            lr = float(rng.choice([0.2, 0.5]))
+        else:
+            rng = np.random.default_rng(9000 + s)
+            Q = int(rng.choice([2, 3, 4]))
+            N = int(rng.choice([300, 600, 1200])) // Q * Q
+            c = float(rng.choice([5.0, 8.0]))
+            pairs, cin, cout = synth.planted_partition(N, Q, c, float(rng.choice([0.05, 0.2])), 300 + s)
+            cab0 = synth.cab_matrix(Q, cin * rng.uniform(0.8, 1.2), cout * rng.uniform(0.8, 1.5))
+            lr = 0.3
+        tc = synth.true_conf(N, Q)
+        na = np.array(synth.group_sizes(N, Q), dtype=np.uint32)
+        og = orc.Graph.from_edges(pairs, N)
+        ob = orc.OracleBP(og, Q, 0)
+        ob.init_messages(0, None, tc, orc.Rng(s))
+        ob.set_params(cab0, na, 1.0)
+        steps, f = ob.learning(1e-6, 60, lr, 1.0, None, sync=True, series_K=0)
+        if ob.learn_unconverged() == 0 and np.isfinite(f):
+            return dict(seed=s, Q=Q, N=N, pairs=pairs, tc=tc, cab0=cab0, na=na, lr=lr, rng=rng, oracle=ob, steps=steps, f=f)
+    raise AssertionError("no regular instance among 50 draws")
+
+
 @pytest.mark.parametrize("seed", _seeds("SBMBP_FUZZ_LEARN_SEEDS", (500, 24)))
 def test_random_instance_learning_against_the_oracle(S, orc, seed):
     """-m learn on random planted instances (Q = 2..6, dc 0, random start parameters): the engine follows the oracle's
     SYNCHRONOUS EM run step for step (same number of EM steps, same learned parameters)"""
-    from sbm_bp_amd import synth
-    rng = np.random.default_rng(7000 + seed)
-    Q = int(rng.choice([2, 3, 4, 6]))
-    N = int(rng.choice([120, 300, 600])) // Q * Q
-    c = float(rng.choice([4.0, 7.0, 10.0]))
-    eps = float(rng.choice([0.05, 0.15, 0.3]))
-    pairs, cin, cout = synth.planted_partition(N, Q, c, eps, 100 + seed)
-    tc = synth.true_conf(N, Q)
-    cab0 = synth.cab_matrix(Q, cin * rng.uniform(0.7, 1.3), cout * rng.uniform(0.7, 1.6))
-    na = np.array(synth.group_sizes(N, Q), dtype=np.uint32)
-    lr, lcrit, tmax = float(rng.choice([0.2, 0.5])), 1e-6, 60
-    g = S.Graph.from_edges(pairs, N)
-    og = orc.Graph.from_edges(pairs, N)
+    t = _learn_instance(orc, seed, "single")
+    Q, N, lcrit, tmax = t["Q"], t["N"], 1e-6, 60
+    g = S.Graph.from_edges(t["pairs"], N)
     bm = S.blockmodel_t(g, Q, 0)
-    # where BP itself does not converge within tmax sweeps (hard or unidentifiable instances) the EM run is a chaotic
-    # trajectory: last-bit differences in the arithmetic grow by many orders of magnitude over tens of EM steps (measured:
-    # 1e-16 -> 1e-7 within six steps, tools/trace_learn_instance.py), so step-for-step agreement means nothing there
-    def chaotic():
-        probe = orc.OracleBP(og, Q, 0)
-        probe.init_messages(0, None, tc, orc.Rng(seed))
-        probe.set_params(cab0, na, 1.0)
-        probe.set_field_mix(0.3)
-        return probe.converge_sync(lcrit, tmax, 1.0)[0] < 0
     bp = S.bp_basic()
-    bp.init_messages(bm, 0, None, tc, seed)
-    st = S.bp_blockmodel_state(cab0, na)
-    res = bp.learning(bm, st, lcrit, tmax, lr, 1.0)
-    ob = orc.OracleBP(og, Q, 0)
-    ob.init_messages(0, None, tc, orc.Rng(seed))
-    ob.set_params(cab0, na, 1.0)
-    steps, f = ob.learning(lcrit, tmax, lr, 1.0, None, sync=True, series_K=0)
+    bp.init_messages(bm, 0, None, t["tc"], t["seed"])
+    res = bp.learning(bm, S.bp_blockmodel_state(t["cab0"], t["na"]), lcrit, tmax, t["lr"], 1.0)
+    steps, f = t["steps"], t["f"]
     cab, na1 = bp.get_params()
-    ocab, ona = ob.get_params()
-    if not np.isfinite(f):
-        assert not np.isfinite(res.free_energy)
-        return
-    ok = abs(res.em_steps - steps) <= 1
-    if ok and res.em_steps == steps and steps < tmax:  # a run that hits the step limit is still moving: nothing to pin there
+    ocab, ona = t["oracle"].get_params()
+    assert abs(res.em_steps - steps) <= 1, (res.em_steps, steps)
+    if res.em_steps == steps and steps < tmax:  # a run that hits the step limit is still moving: nothing to pin there
         # group sizes are truncated to integers every EM step (bp.cpp:60-66): a last-bit difference can move one vertex
-        ok = np.abs(na1.astype(np.int64) - ona.astype(np.int64)).max() <= 1
-        if ok and list(na1) == list(ona):
-            ok = np.abs(cab - ocab).max() < 1e-5 * np.abs(ocab).max() and abs(res.free_energy - f) < 1e-7 * max(1.0, abs(f))
-    if not ok and chaotic():
-        pytest.skip("BP does not converge within tmax on this instance: the EM trajectory is chaotic, rounding decides")
-    assert ok, (res.em_steps, steps, na1, ona, cab, ocab)
+        assert np.abs(na1.astype(np.int64) - ona.astype(np.int64)).max() <= 1, (na1, ona)
+        if list(na1) == list(ona):
+            assert np.abs(cab - ocab).max() < 1e-5 * np.abs(ocab).max(), (cab, ocab)
+            assert abs(res.free_energy - f) < 1e-7 * max(1.0, abs(f))
 
 
 @pytest.mark.parametrize("seed", _seeds("SBMBP_FUZZ_SHARD_LEARN_SEEDS", (800, 10)))
-def test_random_instance_sharded_learning_against_the_single_engine(S, seed):
+def test_random_instance_sharded_learning_against_the_single_engine(S, orc, seed):
     """-m learn over 2-4 ranks follows the single engine's EM run (same schedule; only the summation order of the Q field sums
     differs, which an EM run of tens of steps can amplify up to one vertex in the truncated group sizes)"""
-    from sbm_bp_amd import synth
     from sbm_bp_amd.distributed import LocalShards
-    rng = np.random.default_rng(9000 + seed)
-    Q = int(rng.choice([2, 3, 4]))
-    N = int(rng.choice([300, 600, 1200])) // Q * Q
-    c = float(rng.choice([5.0, 8.0]))
-    pairs, cin, cout = synth.planted_partition(N, Q, c, float(rng.choice([0.05, 0.2])), 300 + seed)
-    tc = synth.true_conf(N, Q)
-    cab0 = synth.cab_matrix(Q, cin * rng.uniform(0.8, 1.2), cout * rng.uniform(0.8, 1.5))
-    na = np.array(synth.group_sizes(N, Q), dtype=np.uint32)
-    g = S.Graph.from_edges(pairs, N)
+    t = _learn_instance(orc, seed, "sharded")
+    Q, N, rng = t["Q"], t["N"], t["rng"]
+    g = S.Graph.from_edges(t["pairs"], N)
     bm = S.blockmodel_t(g, Q, 0)
     bp = S.bp_basic()
-    bp.init_messages(bm, 0, None, tc, seed)
-    one = bp.learning(bm, S.bp_blockmodel_state(cab0, na), 1e-6, 60, 0.3, 1.0)
+    bp.init_messages(bm, 0, None, t["tc"], t["seed"])
+    one = bp.learning(bm, S.bp_blockmodel_state(t["cab0"], t["na"]), 1e-6, 60, 0.3, 1.0)
     cab1, na1 = bp.get_params()
     sb = LocalShards(g, Q, 0, int(rng.integers(2, 5)), n_chunks=int(rng.integers(1, 5)))
-    sb.init_messages(0, None, tc, seed, False)
-    sb.expand_bp_params(cab0, na, 1.0)
+    sb.init_messages(0, None, t["tc"], t["seed"], False)
+    sb.expand_bp_params(t["cab0"], t["na"], 1.0)
     b = sb.learning(1e-6, 60, 0.3)
     sb.close()
-    ok = abs(one.em_steps - b["em_steps"]) <= 1
-    if ok and one.em_steps == b["em_steps"] and one.status == 1 and b["status"] == 1 and list(na1) == list(b["na"]):
-        ok = (np.abs(cab1 - b["cab"]).max() < 1e-7 * np.abs(cab1).max() and abs(one.overlap - b["overlap"]) < 1e-9
-              and abs(one.free_energy - b["free_energy"]) < 1e-9 * max(1.0, abs(one.free_energy)))
-    if not ok:
-        # a halo marginal arrives with its last component restored as 1 - sum (one ulp off): where BP does not converge within
-        # the sweep limit the EM trajectory is chaotic and that ulp decides (see the single-engine learn test above)
-        probe = S.bp_basic()
-        probe.init_messages(bm, 0, None, tc, seed)
-        probe.expand_bp_params(S.bp_blockmodel_state(cab0, na))
-        probe.set_schedule(0.3, 1)
-        if probe.converge(1e-6, 60, 1.0)[0] < 0:
-            pytest.skip("BP does not converge within tmax on this instance: the EM trajectory is chaotic")
-    assert ok, (one.em_steps, b["em_steps"], na1, b["na"])
+    assert abs(one.em_steps - b["em_steps"]) <= 1, (one.em_steps, b["em_steps"])
+    if one.em_steps == b["em_steps"] and one.status == 1 and b["status"] == 1 and list(na1) == list(b["na"]):
+        assert np.abs(cab1 - b["cab"]).max() < 1e-7 * np.abs(cab1).max()
+        assert abs(one.overlap - b["overlap"]) < 1e-9
+        assert abs(one.free_energy - b["free_energy"]) < 1e-9 * max(1.0, abs(one.free_energy))
+    else:
+        assert np.abs(na1.astype(np.int64) - np.asarray(b["na"]).astype(np.int64)).max() <= 1, (na1, b["na"])

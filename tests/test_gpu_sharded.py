@@ -59,6 +59,24 @@ def test_sharded_equals_unsharded_and_reference(orc, name, world):
     assert sb.stats()[0].psi_form_sweeps > 0
 
 
+@pytest.mark.parametrize("world", [2, 5])
+def test_adaptive_relaxation_is_taken_identically_on_every_rank(S, orc, world):
+    """hub_dc0 (plain Jacobi oscillates): every rank folds the same all-gathered sums, so all of them lower the field mix on the
+    same sweep without talking about it, and the sharded run lands where the single engine and the reference do"""
+    a, r, g, cab, na, psi0, msg0 = _problem(orc, "hub_dc0_tight_seed0")
+    one = _sharded(g, a, cab, na, psi0, msg0, 1)
+    sb = _sharded(g, a, cab, na, psi0, msg0, world)
+    n1, l1 = one.converge(a["crit"], a["tmax"], 1.0)
+    nk, lk = sb.converge(a["crit"], a["tmax"], 1.0, check_every=5)
+    assert n1 >= 0 and nk == n1 and one.relaxation() == sb.relaxation() == (1, -1)
+    psi = sb.global_state()[0]
+    assert np.abs(psi - one.global_state()[0]).max() < 1e-10
+    assert best_perm_diff(psi, np.array(r["psi"]).reshape(psi.shape))[0] < 1e-9
+    assert abs(sb.compute_free_energy() - r["f"]) < 1e-9 * abs(r["f"])
+    sb.close()
+    one.close()
+
+
 def test_sharded_matches_single_engine_fixed_point(S, orc):
     a, r, g, cab, na, psi0, msg0 = _problem(orc, "q4_tight_seed0")
     sb = _sharded(g, a, cab, na, psi0, msg0, 3)
