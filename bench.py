@@ -156,7 +156,10 @@ def free_port():
 def self_launch(n):
     """`python bench.py --gpus N` from a bare shell: start N fresh rank processes (one per GPU) with the environment
     torch.distributed.run would give them. This parent never touches the GPU and never re-execs itself; rank 0's JSON
-    line reaches stdout through the inherited descriptor."""
+    line reaches stdout through the inherited descriptor. All children are polled together: the first one that exits
+    non-zero (an out-of-memory rank, a failed RCCL init, its own watchdog) takes the others down - they would sit in a
+    collective waiting for it - and its code is the parent's. SIGTERM / SIGINT to the parent do the same."""
+    import signal
     port = free_port()
     procs = []
     for r in range(n):
@@ -164,20 +167,82 @@ def self_launch(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SBMBP_SELF_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    try:
-        for p in procs:
-            p.wait()
-            rc = rc or p.returncode
-            if p.returncode != 0:  # one rank failed: the others would wait for it in a collective
-                for q in procs:
-                    if q.poll() is None:
-                        q.terminate()
-    finally:
+
+    def stop_all(grace=10.0):
         for q in procs:
             if q.poll() is None:
+                q.terminate()
+        t_end = time.monotonic() + grace
+        for q in procs:
+            while q.poll() is None and time.monotonic() < t_end:
+                time.sleep(0.05)
+            if q.poll() is None:
                 q.kill()
+        for q in procs:
+            q.wait()
+
+    signalled = []
+
+    def on_signal(signum, _frame):
+        signalled.append(signum)
+
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, on_signal)
+    rc = 0
+    try:
+        while True:
+            codes = [q.poll() for q in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if signalled:
+                rc = 128 + signalled[0]
+                break
+            if bad:
+                rc = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            time.sleep(0.1)
+    finally:
+        stop_all()
     return rc
+
+
+class Watchdog:
+    """Per-phase deadline inside every rank process (it works the same under torch.distributed.run, where this file is not
+    the parent). A daemon thread that never touches the GPU: when a phase outlives its deadline - a rank stuck in an RCCL
+    collective whose peer died, a hung kernel - it prints ONE diagnostic JSON line naming the phase and ends the process with
+    code 3; the launcher (self_launch above, or torchrun) then takes the other ranks down. Nothing is re-executed.
+    SBMBP_PHASE_DEADLINE_S scales every deadline (default 1.0; 0 switches the watchdog off)."""
+    DEADLINES = {"import": 600, "rendezvous": 300, "setup": 1800, "chunk_trials": 1800, "warmup": 300, "timed": 600,
+                 "converge": 900, "cpu_baseline": 900, "report": 300}
+
+    def __init__(self, rank, world):
+        import threading
+        self.rank, self.world = rank, world
+        self.scale = float(os.environ.get("SBMBP_PHASE_DEADLINE_S", "1.0"))
+        self.phase, self.t0 = "import", time.monotonic()
+        self.lock = threading.Lock()
+        if self.scale > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def enter(self, phase):
+        with self.lock:
+            self.phase, self.t0 = phase, time.monotonic()
+
+    def _run(self):
+        while True:
+            time.sleep(1.0)
+            with self.lock:
+                phase, el = self.phase, time.monotonic() - self.t0
+            if phase == "done":
+                return
+            limit = self.DEADLINES.get(phase.split(":")[0], 600) * self.scale
+            if el > limit:
+                sys.stdout.write(json.dumps({"error": "watchdog", "phase": phase, "rank": self.rank, "n_gpus": self.world,
+                                             "elapsed_s": round(el, 1), "deadline_s": limit,
+                                             "note": "a phase outlived its deadline; this rank exits with code 3 and the launcher ends the others"}) + "\n")
+                sys.stdout.flush()
+                os._exit(3)
 
 
 def main():
@@ -201,13 +266,14 @@ def main():
     if "RANK" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args.gpus))
 
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dog = Watchdog(rank, world)
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # SBMBP_REHEARSAL=1 (development aid, never the measured configuration): all ranks share cuda:0 and the
@@ -221,6 +287,15 @@ def main():
         os.environ["MASTER_PORT"] = str(free_port())
     if not args.dry_run:
         torch.cuda.set_device(local_rank)
+    dog.enter("rendezvous")
+    # fault injection for the tests of the launcher and the watchdog (tests/test_sharded_cpu.py): "exit:<rank>:<code>" ends
+    # that rank before the rendezvous, "hang:<rank>" parks it there
+    inject = os.environ.get("SBMBP_BENCH_INJECT", "").split(":")
+    if len(inject) >= 2 and inject[1] == str(rank):
+        if inject[0] == "exit":
+            sys.exit(int(inject[2]))
+        if inject[0] == "hang":
+            time.sleep(3600)
     if sharded:
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -234,6 +309,7 @@ def main():
     N, Q, c, eps, dc, gseed = WORKLOADS[args.workload]
     if args.dry_run:
         return dry_run(args, rank, world, N, Q, c, eps, dc, gseed)
+    dog.enter("setup")
     t0 = time.perf_counter()
     tc = synth.true_conf(N, Q)
     if not sharded:
@@ -285,14 +361,29 @@ def main():
         chunk_trials = None
         if world > 1 and not os.environ.get("SBMBP_SHARD_CHUNKS"):
             chunk_trials, runner, graph = {}, None, None
-            # "4p": four chunks with stream priorities (SBMBP_SHARD_PRIO=1: chunks complete one after the other
-            # and their halo leaves earlier, at 6 - 10 % more kernel time); the library reads the switch when a plan is created
             # "4s": four chunks on one stream (SBMBP_SHARD_STREAMS=1): they complete strictly one after the other, without
-            # the second stream that fills their tails
-            # (a plan costs 3 s per rank at 8 ranks of C3 and 12 s at 2 ranks: six candidates)
-            for nc in (1, 2, 4, 8, "4p", "4s"):
-                os.environ["SBMBP_SHARD_PRIO"] = "1" if str(nc).endswith("p") else "0"
-                os.environ["SBMBP_SHARD_STREAMS"] = "1" if str(nc).endswith("s") else "2"
+            # the second stream that fills their tails. An exported SBMBP_SHARD_STREAMS / SBMBP_SHARD_PRIO pins that switch: the
+            # variants that would overwrite it are skipped. (Round 2 also tried "4p", stream priorities: dropped from the
+            # automatic set. Alone on a GPU it costs 6 - 10 % of the sweep, and the one record of it beside other ranks -
+            # profiles/r02_small_bench_3ranks_rehearsal.json, three PROCESSES sharing one GPU - shows 25 ms per sweep against
+            # 1.5 - 2.8 ms for every other variant: a high-priority stream of one process starves the low-priority streams of
+            # the others while all of them wait for each other in the per-sweep collective. SBMBP_SHARD_PRIO=1 still exists as
+            # an opt-in for a node where every rank has its GPU to itself.)
+            # (a plan costs 3 s per rank at 8 ranks of C3 and 12 s at 2 ranks: five candidates)
+            pinned_streams = os.environ.get("SBMBP_SHARD_STREAMS")
+            variants = [1, 2, 4, 8] + ([] if pinned_streams else ["4s"])
+            # two plans resident at once (the best so far and the candidate): at the capacity workloads the old best is
+            # closed BEFORE the next candidate is built, and the winner is rebuilt at the end
+            tight = N >= 50_000_000
+            best_nc = None
+            for nc in variants:
+                dog.enter("chunk_trials:%s" % nc)
+                if not pinned_streams:
+                    os.environ["SBMBP_SHARD_STREAMS"] = "1" if str(nc).endswith("s") else "2"
+                if tight and runner is not None:
+                    graph = runner.graph
+                    runner.close()
+                    runner = None
                 cand = ShardedBP.synthetic(N, Q, c, eps, gseed, dc=dc, seed=1234, comm=comm, device=local_rank,
                                            n_chunks=int(str(nc).rstrip("ps")), graph=graph)
                 graph = cand.graph
@@ -309,14 +400,22 @@ def main():
                     dist.all_reduce(t_loc, op=dist.ReduceOp.MAX)
                     best_try = float(t_loc.item()) if best_try is None else min(best_try, float(t_loc.item()))
                 chunk_trials[nc] = best_try / 5 * 1e3
-                if runner is None or chunk_trials[nc] < 0.98 * chunk_trials[best_nc]:
+                if best_nc is None or chunk_trials[nc] < 0.98 * chunk_trials[best_nc]:
                     if runner is not None:
                         runner.close()
                     runner, best_nc = cand, nc
+                elif tight:
+                    cand.close()
+                    runner = None
                 else:
                     cand.close()
-            os.environ["SBMBP_SHARD_PRIO"] = "1" if str(best_nc).endswith("p") else "0"  # (what the chosen plan was created with)
-            os.environ["SBMBP_SHARD_STREAMS"] = "1" if str(best_nc).endswith("s") else "2"
+            if not pinned_streams:
+                os.environ["SBMBP_SHARD_STREAMS"] = "1" if str(best_nc).endswith("s") else "2"  # (what the chosen plan is created with)
+            if runner is None or (tight and int(str(best_nc).rstrip("ps")) != runner.info.n_chunks):
+                if runner is not None:
+                    runner.close()
+                runner = ShardedBP.synthetic(N, Q, c, eps, gseed, dc=dc, seed=1234, comm=comm, device=local_rank,
+                                             n_chunks=int(str(best_nc).rstrip("ps")), graph=graph)
             runner.init_messages_device(1234, tc)
             runner.expand_bp_params(runner.cab, runner.na, 1.0)
         else:
@@ -340,11 +439,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    dog.enter("warmup")
     runner.set_timing(False)
     runner.sweep(args.warmup, 1.0, want_diff=False)
     runner.reset_stats()
     runner.set_timing(True)
     barrier()
+    dog.enter("timed")
     t1 = time.perf_counter()
     runner.sweep(args.steps, 1.0, want_diff=False)
     barrier()
@@ -361,6 +462,7 @@ def main():
     converge = None
     if args.converge:
         # the metric as SURVEY 8(d) defines it: the whole converge phase from the initial state, host loop included
+        dog.enter("converge")
         runner.set_timing(False)
         reinit()
         barrier()
@@ -373,7 +475,13 @@ def main():
         # partition invariant, so `sweeps` and `overlap` of an N-GPU line must equal the 1-GPU line's
         converge = {"crit": CONV_CRIT, "sweeps": sweeps, "converged": niter >= 0, "wall_ms": dtc * 1e3,
                     "edge_msg_per_s": sweeps * E2_total / dtc, "ms_per_sweep": dtc * 1e3 / sweeps,
-                    "overlap": runner.compute_overlap()}
+                    "overlap": runner.compute_overlap(),
+                    # the timed converge starts from the DEVICE initial state (random marginals, every message = its sender's
+                    # marginal), not from the reference's flag-0 state of independent random messages per edge (bin/bp
+                    # reproduces that one bit for bit; it needs a few sweeps more: README)
+                    "init": "device: random marginals, message = sender's marginal (not the reference's -i 0 state)",
+                    # adaptive relaxation: (field level, generic level) the run ended on; [0, -1] = plain synchronous sweeps
+                    "relaxation": list(runner.relaxation()[:2])}
 
     if rank == 0:
         kname = ("k_sweep_psi<%d>" if st.psi_form_sweeps else "k_sweep<%d>") % Q
@@ -420,12 +528,16 @@ def main():
             out["converge"] = converge
             out["sweeps_to_converge"] = converge["sweeps"] if converge["converged"] else -1
         if world == 1 and not args.no_cpu_baseline:
+            dog.enter("cpu_baseline")
             out["cpu_baseline"] = cpu_baseline(Q, c, eps)  # plain planted partition of the same Q, c (also for C4)
+        dog.enter("report")
         print(json.dumps(out), flush=True)
+    dog.enter("report")
     if sharded:
         runner.close()
         dist.barrier()
         dist.destroy_process_group()
+    dog.enter("done")
 
 
 def dry_run(args, rank, world, N, Q, c, eps, dc, gseed):

@@ -207,15 +207,17 @@ int sbmbp_reset_stats(sbmbp_engine_t *e);
 int sbmbp_set_timing(sbmbp_engine_t *e, int on);
 
 /* ---------------------------------------------------------------------------------------------
- * Vertex-range sharding (one engine per GPU, one process per GPU). No reference counterpart: the
+ * Vertex-range sharding: the per-shard STEPS (one engine per GPU). No reference counterpart: the
  * reference is single-process. A shard owns a contiguous range of rows, their out-messages and
  * marginals; the marginals of remote neighbours ("halo") live behind the owned rows in the same
- * table, so nbr_local indexes one array. The caller (sbm-bp_amd/distributed.py) moves data
- * between shards with torch.distributed (RCCL): halo marginals once per sweep (all-to-all) and
- * the Q+1 reduction values (all-reduce); the shard entry points below are the steps in between.
- * Sharded engines run the marginal-gather sweep only (damping 1, cab > 0, no clamped rows,
- * deg_corr_flag 0/1) with the declared initial state taken as (psi^0, m^-1).
- * All device buffers named here are caller-owned (torch tensors) so collectives can address them.
+ * table, so nbr_local indexes one array, and the message records received for the cut edges sit
+ * behind the own records of each message buffer, so rev_local does too. The caller of these steps is
+ * the C++ multi-GPU driver further down (sbmbp_dist_*, csrc/dist.hip), which moves the data between
+ * the shards itself over its RCCL communicators (sbmbp_comm_*): boundary marginals (marginal-gather
+ * sweep) or cut-edge messages (message-gather sweep) once per sweep, the Q+1 reduction values by one
+ * all-gather. Every sweep form of the single engine runs sharded: damping, clamped rows,
+ * deg_corr_flag 2, zeros in cab take the message-gather sweep. The device buffers named in the
+ * descriptor are owned by the caller (the driver) so that its collectives can address them.
  * ------------------------------------------------------------------------------------------- */
 typedef struct sbmbp_shard_desc {
     uint32_t n_global;          /* vertices of the whole graph (field scaling, eta) */

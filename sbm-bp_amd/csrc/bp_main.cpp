@@ -19,6 +19,9 @@
 #include <sstream>
 #include <string>
 #include <thread>
+#include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <vector>
 
 #include "../../include/sbmbp.h"
@@ -347,18 +350,56 @@ int main(int argc, char const *argv[]) {
         std::vector<uint32_t> na_out(na);
         sbmbp_stats st0{};
         const auto t0 = std::chrono::steady_clock::now();
+        // A rank can fail OUTSIDE a collective (out of memory in sbmbp_dist_create, a bad initial state): on RCCL its peers
+        // would queue collectives that spin on it and then sit in hipEventSynchronize for ever. Two guards: (1) the rank
+        // threads AGREE on the set-up before the first collective is queued - a failed rank makes all of them leave; (2) a
+        // rank that fails later aborts EVERY communicator of the run, not only its own (ncclCommAbort is safe from another
+        // thread), so the kernels of the healthy ranks end and their host threads return an error.
+        std::mutex mu;
+        std::condition_variable cv;
+        int arrived = 0, generation = 0;
+        bool any_failed = false;
+        auto agree = [&](bool ok) {  // all rank threads meet here; false when any of them has failed
+            std::unique_lock<std::mutex> lk(mu);
+            if (!ok) any_failed = true;
+            const int gen = generation;
+            if (++arrived == n_gpus) { arrived = 0; ++generation; cv.notify_all(); }
+            else cv.wait(lk, [&] { return generation != gen; });
+            return !any_failed;
+        };
+        auto abort_all = [&]() {
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto *c : comms) if (c) sbmbp_comm_abort(c);
+        };
+        const char *inject = std::getenv("SBMBP_INJECT_RANK_FAIL");  // tests: "<rank>:setup" or "<rank>:run"
         auto rank_main = [&](int r) {
             const int dev = r % n_dev;
             sbmbp_dist_t *d = nullptr;
             int e = SBMBP_OK;
             auto step = [&](int code) { if (e == SBMBP_OK && code != SBMBP_OK) { e = code; errs[r] = sbmbp_last_error(); } return e == SBMBP_OK; };
-            if (!local) step(sbmbp_comm_init_rank(&comms[r], comm_id, n_gpus, r, dev));
+            auto injected = [&](const char *where) {
+                return inject && std::atoi(inject) == r && std::strstr(inject, where) != nullptr;
+            };
+            if (!local) {
+                sbmbp_comm_t *c = nullptr;
+                step(sbmbp_comm_init_rank(&c, comm_id, n_gpus, r, dev));
+                std::lock_guard<std::mutex> lk(mu);
+                comms[r] = c;
+            }
             if (e == SBMBP_OK) step(sbmbp_dist_create(&d, comms[r], graph, Q, deg_corr_flag, dev, 0));
+            if (e == SBMBP_OK && injected("setup")) { e = SBMBP_ERR_NOMEM; errs[r] = "injected failure (SBMBP_INJECT_RANK_FAIL)"; }
             if (e == SBMBP_OK) step(sbmbp_dist_init_messages(d, bp_messages_init_flag, beliefs.size() == N ? beliefs.data() : nullptr, true_conf.data(),
                                                              seed, mode == "learn" ? 0 : 1));
             if (e == SBMBP_OK) step(sbmbp_dist_set_params(d, cab_full.data(), na.data(), beta));
             if (e == SBMBP_OK) step(sbmbp_dist_set_schedule(d, num("field_mix", 1.0), unsigned(num("check_every", 8))));
             if (e == SBMBP_OK && var_map.count("gather") && var_map.get("gather")[0] == "messages") step(sbmbp_dist_set_gather_mode(d, 1));
+            if (!agree(e == SBMBP_OK)) {  // some rank failed during set-up: nobody queues a collective
+                if (e == SBMBP_OK) { e = SBMBP_ERR_COMM; errs[r] = "another rank failed during set-up"; }
+                if (d) sbmbp_dist_destroy(d);
+                rcs[r] = e;
+                return;
+            }
+            if (injected("run")) { e = SBMBP_ERR_NOMEM; errs[r] = "injected failure (SBMBP_INJECT_RANK_FAIL)"; }
             if (e == SBMBP_OK && mode == "infer") {
                 sbmbp_infer_result res{};
                 if (step(sbmbp_dist_inference(d, bp_conv_crit, time_conv, dumping_rate, &res)) && r == 0) ires = res;
@@ -374,7 +415,7 @@ int main(int argc, char const *argv[]) {
                 }
             }
             if (e == SBMBP_OK && r == 0) step(sbmbp_dist_get_stats(d, &st0));
-            if (e != SBMBP_OK && comms[r]) sbmbp_comm_abort(comms[r]);  // nobody waits for a rank that gave up
+            if (e != SBMBP_OK) abort_all();  // nobody waits for a rank that gave up: every communicator of the run ends
             if (d) sbmbp_dist_destroy(d);
             rcs[r] = e;
         };

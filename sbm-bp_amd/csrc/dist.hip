@@ -313,6 +313,8 @@ struct sbmbp_comm {
     int kind = 0;  // 0 rccl, 1 local, 2 callbacks, 3 null (measurement: one rank of a W-rank plan alone, peers never answer)
     int rank = 0, world = 1, device = -1;
     ncclComm_t halo = nullptr, red = nullptr;
+    bool one_comm = false;             // SBMBP_SHARD_ONE_COMM=1: red IS halo (both kinds of traffic serialised on one communicator)
+    std::atomic<bool> aborted{false};  // sbmbp_comm_abort may come from ANOTHER thread (a rank that failed outside a collective)
     std::shared_ptr<local_group> grp;
     sbmbp_comm_callbacks cb{};
     double *h_a = nullptr, *h_b = nullptr;  // page-locked staging (callbacks)
@@ -342,15 +344,26 @@ int comm_exchange(sbmbp_comm *c, const double *send, const u64 *send_counts, dou
     const int W = c->world;
     if (W == 1 || c->kind == 3) return SBMBP_OK;
     if (c->kind == 0) {
+        // The group is ALWAYS closed: returning between ncclGroupStart and ncclGroupEnd would leave this thread's group open
+        // and queue every later RCCL call of the thread - abort and destroy included - into it. The first error is kept.
+        // (Two communicators run side by side on one device: `halo` here on the exchange stream, `red` for the all-gather /
+        // all-reduce on the compute stream, so that the two kinds of traffic never queue behind each other inside one
+        // communicator. Their kernels must be co-resident for that; SBMBP_SHARD_ONE_COMM=1 puts both on ONE communicator and
+        // serialises them by stream order, as a fallback for a node where they are not - sbmbp_comm_init_rank.)
         NCCLCHK(ncclGroupStart());
+        ncclResult_t first = ncclSuccess;
         u64 so = 0, ro = 0;
-        for (int p = 0; p < W; ++p) {
-            if (send_counts[p]) NCCLCHK(ncclSend(send + so * width, send_counts[p] * width, ncclDouble, p, c->halo, stream));
-            if (recv_counts[p]) NCCLCHK(ncclRecv(recv + ro * width, recv_counts[p] * width, ncclDouble, p, c->halo, stream));
+        for (int p = 0; p < W && first == ncclSuccess; ++p) {
+            if (send_counts[p]) first = ncclSend(send + so * width, send_counts[p] * width, ncclDouble, p, c->halo, stream);
+            if (first == ncclSuccess && recv_counts[p]) first = ncclRecv(recv + ro * width, recv_counts[p] * width, ncclDouble, p, c->halo, stream);
             so += send_counts[p];
             ro += recv_counts[p];
         }
-        NCCLCHK(ncclGroupEnd());
+        const ncclResult_t end = ncclGroupEnd();
+        if (first != ncclSuccess || end != ncclSuccess) {
+            set_error(std::string("halo exchange (grouped ncclSend/ncclRecv): ") + ncclGetErrorString(first != ncclSuccess ? first : end));
+            return SBMBP_ERR_COMM;
+        }
         return SBMBP_OK;
     }
     if (c->kind == 1) {
@@ -490,7 +503,10 @@ int sbmbp_comm_init_rank(sbmbp_comm_t **out, const void *id, int n_ranks, int ra
     ncclUniqueId ids[2];
     std::memcpy(ids, id, sizeof ids);
     ncclResult_t r = ncclCommInitRank(&c->halo, n_ranks, ids[0], rank);
-    if (r == ncclSuccess) r = ncclCommInitRank(&c->red, n_ranks, ids[1], rank);
+    const char *one = std::getenv("SBMBP_SHARD_ONE_COMM");
+    c->one_comm = one && std::atoi(one) != 0;
+    if (c->one_comm) c->red = c->halo;  // fallback for a node where two RCCL kernels of one device are not co-resident
+    else if (r == ncclSuccess) r = ncclCommInitRank(&c->red, n_ranks, ids[1], rank);
     if (r != ncclSuccess) {
         set_error(std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
         if (c->halo) ncclCommDestroy(c->halo);
@@ -541,8 +557,10 @@ int sbmbp_comm_init_null(sbmbp_comm_t **out, int n_ranks, int rank) {
 
 void sbmbp_comm_destroy(sbmbp_comm_t *c) {
     if (!c) return;
-    if (c->halo) ncclCommDestroy(c->halo);
-    if (c->red) ncclCommDestroy(c->red);
+    if (!c->aborted.load()) {  // ncclCommAbort has already freed an aborted communicator
+        if (c->halo) ncclCommDestroy(c->halo);
+        if (c->red && !c->one_comm) ncclCommDestroy(c->red);
+    }
     if (c->kind == 1 && c->grp) {
         local_group::slot &me = c->grp->slots[c->rank];
         if (me.ready) (void)hipEventDestroy(me.ready);
@@ -558,9 +576,12 @@ void sbmbp_comm_destroy(sbmbp_comm_t *c) {
 void sbmbp_comm_abort(sbmbp_comm_t *c) {
     if (!c) return;
     if (c->kind == 1 && c->grp) c->grp->fail();
-    if (c->kind == 0) {
-        if (c->halo) { ncclCommAbort(c->halo); c->halo = nullptr; }
-        if (c->red) { ncclCommAbort(c->red); c->red = nullptr; }
+    if (c->kind == 0 && !c->aborted.exchange(true)) {
+        // ncclCommAbort is safe from a thread other than the one driving the communicator: kernels spinning on a dead peer
+        // end, the owner's queued calls return an error. The handles stay where they are (the owner may be reading them);
+        // sbmbp_comm_destroy skips what was aborted.
+        if (c->halo) ncclCommAbort(c->halo);
+        if (c->red && !c->one_comm) ncclCommAbort(c->red);
     }
 }
 

@@ -20,8 +20,9 @@ def built():
     assert os.path.exists(BP)
 
 
-def run(*args):
-    p = subprocess.run([BP] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+def run(*args, env=None):
+    p = subprocess.run([BP] + [str(a) for a in args], capture_output=True, text=True, timeout=300,
+                       env=None if env is None else dict(os.environ, **env))
     return p.returncode, p.stdout, p.stderr
 
 
@@ -225,6 +226,19 @@ def test_gpus_flag_shards_the_run_and_prints_the_same_lines(extra):
     e1, f1, o1, n1 = _line(out1)
     e3, f3, o3, n3 = _line(out3)
     assert n1 == n3 and abs(f1 - f3) < 1e-11 and abs(e1 - e3) < 1e-11 and abs(o1 - o3) < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("where", ["1:setup", "2:run"])
+def test_gpus_flag_a_failing_rank_ends_the_run(where):
+    """a rank that fails outside a collective - during set-up, or after the others have started their sweeps - must end the
+    whole run with its error, not leave the other rank threads waiting for it: set-up is agreed on before the first
+    collective, and a later failure aborts EVERY communicator of the run"""
+    import time
+    t0 = time.monotonic()
+    rc, out, err = run(*MATCHED, "--gpus", 3, env={"SBMBP_INJECT_RANK_FAIL": where, "SBMBP_LOCAL_TIMEOUT_S": "20"})
+    assert rc == 1 and out == "" and ("rank %s" % where[0]) in err and "injected failure" in err, err
+    assert time.monotonic() - t0 < 120
 
 
 @pytest.mark.gpu

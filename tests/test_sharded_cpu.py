@@ -162,3 +162,49 @@ def test_bench_self_launches_its_ranks_dry_run():
     line = [l for l in pr.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["dry_run"] and out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["plans_consistent"]
+
+
+def _bench_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_bench_launcher_ends_the_other_ranks_when_one_dies():
+    """a rank that dies outside a collective (out of memory, a failed RCCL init) leaves its peers waiting for it in the
+    rendezvous or a collective: the launcher polls all its children, takes the others down and exits with the failed rank's
+    code instead of hanging (round 2 waited for rank 0 first, forever)"""
+    import time
+    t0 = time.monotonic()
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-run", "--workload", "small"],
+                        env=_bench_env(SBMBP_BENCH_INJECT="exit:2:7"), timeout=240, capture_output=True, text=True)
+    assert pr.returncode == 7, (pr.returncode, pr.stderr[-1500:])
+    assert time.monotonic() - t0 < 200  # well inside the rendezvous timeout of the surviving ranks
+
+
+def test_bench_watchdog_names_the_phase_of_a_hung_rank():
+    """a rank parked before the rendezvous: every rank's in-process watchdog (a thread that never touches the GPU) ends its
+    process with ONE diagnostic JSON line naming the phase and code 3; the launcher returns that code. Nothing re-executes."""
+    import json
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--workload", "small"],
+                        env=_bench_env(SBMBP_BENCH_INJECT="hang:1", SBMBP_PHASE_DEADLINE_S="0.02"), timeout=240,
+                        capture_output=True, text=True)
+    assert pr.returncode == 3, (pr.returncode, pr.stderr[-1500:])
+    lines = [json.loads(l) for l in pr.stdout.splitlines() if l.startswith("{")]
+    assert lines and all(l.get("error") == "watchdog" for l in lines)
+    assert any(l["phase"] == "rendezvous" for l in lines)
+
+
+def test_bench_launcher_passes_a_sigterm_on():
+    """SIGTERM to the launcher must not orphan the ranks"""
+    import signal
+    import time
+    pr = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--workload", "small"],
+                          env=_bench_env(SBMBP_BENCH_INJECT="hang:0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    time.sleep(8.0)  # the ranks are up (importing torch) or parked
+    pr.send_signal(signal.SIGTERM)
+    rc = pr.wait(timeout=60)
+    assert rc == 128 + signal.SIGTERM
+    # no rank process of that launcher is left behind
+    out = subprocess.run(["ps", "-eo", "ppid,pid,args"], capture_output=True, text=True).stdout
+    assert not [l for l in out.splitlines() if l.split()[0] == str(pr.pid)]
