@@ -75,16 +75,17 @@ def host_info():
     return {"nproc": os.cpu_count(), "cpu_model": model}
 
 
-def cpu_baseline(Q, c, eps, sample_n=1_000_000, sweeps=4):
-    """the reference's converge() on ONE host core (the reference is single-threaded), on a bounded sample of the
-    same graph family (same Q, c, eps at N = 1e6: the reference needs ~220 B of heap per directed edge and 50-70 s per
-    sweep at the benchmarked N = 1e7)"""
+def cpu_baseline(Q, c, eps, sample_n=1_000_000, sweeps=4, gseed=12345, full=None):
+    """the reference's converge() on ONE host core (the reference is single-threaded). Default: a bounded sample of the
+    same graph family (same Q, c, eps at N = 1e6: the reference needs ~220 B of heap per directed edge and ~25 s per sweep
+    at the benchmarked N = 1e7). `full` = a workload name: the benchmarked graph ITSELF (same generator seed, same
+    parameters, BP seed 0), a fixed number of sweeps, as SURVEY 8(d) words it (--cpu-baseline full: minutes, ~20 GB)."""
     import numpy as np
     from sbm_bp_amd import synth
-    pairs, cin, cout = synth.planted_partition(sample_n, Q, c, eps, 12345)
+    pairs, cin, cout = synth.planted_partition(sample_n, Q, c, eps, gseed)
     e2 = 2 * len(pairs)
-    sample = "planted partition N=%d Q=%d c=%g eps=%g (E2=%d), %d asynchronous sweeps, converge() only" % (
-        sample_n, Q, c, eps, e2, sweeps)
+    sample = "%splanted partition N=%d Q=%d c=%g eps=%g (E2=%d), %d asynchronous sweeps, converge() only" % (
+        ("the %s graph itself: " % full) if full else "", sample_n, Q, c, eps, e2, sweeps)
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "bp_ref")
     cabu = []
     for r in range(Q):
@@ -95,14 +96,22 @@ def cpu_baseline(Q, c, eps, sample_n=1_000_000, sweeps=4):
         with tempfile.TemporaryDirectory() as d:
             path = os.path.join(d, "sample.bin")
             np.ascontiguousarray(pairs, dtype=np.uint32).tofile(path)
+            del pairs
             sizes = synth.group_sizes(sample_n, Q)
             argv = [ref_bin, "converge", "l=" + path, "n=" + ",".join(map(str, sizes)),
                     "pa=" + ",".join(repr(1.0 / Q) for _ in range(Q)), "cab=" + ",".join(repr(float(x)) for x in cabu),
                     "d=0", "e=0", "t=%d" % sweeps, "quiet=1"]
+            t0 = time.perf_counter()
             out = subprocess.run(argv, capture_output=True, text=True, check=True).stdout
+            wall = time.perf_counter() - t0
             r = json.loads(out)
-            return {"value": r["edge_msg_per_s"], "unit": "edge-msg/s", "cores": 1, "kind": "reference", "sample": sample,
-                    "host": host}
+            res = {"value": r["edge_msg_per_s"], "unit": "edge-msg/s", "cores": 1, "kind": "reference", "sample": sample,
+                   "host": host}
+            for k in ("load_s", "init_s", "converge_s"):  # the reference's own phases: text/binary load, init_messages, converge()
+                if k in r:
+                    res[k] = r[k]
+            res["wall_s"] = round(wall, 1)
+            return res
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     g = orc.Graph.from_edges(pairs, sample_n)
@@ -214,7 +223,7 @@ class Watchdog:
     code 3; the launcher (self_launch above, or torchrun) then takes the other ranks down. Nothing is re-executed.
     SBMBP_PHASE_DEADLINE_S scales every deadline (default 1.0; 0 switches the watchdog off)."""
     DEADLINES = {"import": 600, "rendezvous": 300, "setup": 1800, "chunk_trials": 1800, "warmup": 300, "timed": 600,
-                 "converge": 900, "cpu_baseline": 900, "report": 300}
+                 "converge": 900, "cpu_baseline": 1800, "report": 300}
 
     def __init__(self, rank, world):
         import threading
@@ -252,6 +261,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "none"],
+                    help="sample (default): the reference's converge() on N = 1e6 of the same family, ~10 s; full: on the "
+                         "benchmarked graph itself for 3 sweeps (SURVEY 8(d); minutes and ~20 GB at C3); none")
     ap.add_argument("--converge", action="store_true", default=True,
                     help="also time one converge(5e-6) from the initial state (after the timed sweeps; default on)")
     ap.add_argument("--no-converge", dest="converge", action="store_false")
@@ -527,9 +539,12 @@ def main():
         if converge is not None:
             out["converge"] = converge
             out["sweeps_to_converge"] = converge["sweeps"] if converge["converged"] else -1
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.cpu_baseline != "none":
             dog.enter("cpu_baseline")
-            out["cpu_baseline"] = cpu_baseline(Q, c, eps)  # plain planted partition of the same Q, c (also for C4)
+            if args.cpu_baseline == "full" and args.workload != "C4":
+                out["cpu_baseline"] = cpu_baseline(Q, c, eps, sample_n=N, sweeps=3, gseed=gseed, full=args.workload)
+            else:
+                out["cpu_baseline"] = cpu_baseline(Q, c, eps)  # plain planted partition of the same Q, c (also for C4)
         dog.enter("report")
         print(json.dumps(out), flush=True)
     dog.enter("report")

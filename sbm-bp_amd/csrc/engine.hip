@@ -102,6 +102,10 @@ struct sbmbp_engine {
     int gather_mode = 0;         // 0 = automatic, 1 = always gather messages (explicit form)
     uint64_t psi_sweeps = 0;     // sweeps executed by k_sweep_psi
     double field_mix = 1.0;
+    // results of the fused reduction pass (k_fe_psi) for the current state: inference and every EM step ask for the site /
+    // edge terms, the adjacent pairs of the non-edge term and the EM numerators one after the other; one pass serves them all
+    struct { bool valid = false, entropy = false, em = false; double se[4] = {0, 0, 0, 0}, adj[2] = {0, 0}; std::vector<double> tri; } fz;
+    int fused_reductions = 1;    // 0: always the separate kernels (SBMBP_FUSED_REDUCTIONS=0)
     bool auto_relax = true;      // adaptive relaxation of converge (sbmbp_set_auto_relax; kernels.h dev_params::ar_*)
     int ar_fl = 0, ar_gl = -1;   // levels the last converge call ended on
     double learn_field_mix = 0.3, learn_snap = 1.0;  // sbmbp_set_learning_schedule
@@ -173,7 +177,15 @@ const double *fold_stage(sbmbp_engine *e, uint32_t *rows, int ncols_sum, int has
 inline int frame_cap(uint32_t Q) { return (Q <= 4 ? FTPB : SBMBP_FRAME_TPB_HI) * (Q <= 2 ? SBMBP_EPT_LO : (Q <= 4 ? SBMBP_EPT_MID : (Q <= 8 ? SBMBP_EPT_HI : 1))); }
 inline int frame_rcap(uint32_t Q) { const int cap = frame_cap(Q); return cap / 2 > 64 ? cap / 2 : 64; }
 
-// Q/dc dispatch over the templated kernels
+// Q/dc dispatch over the templated kernels. -DSBMBP_ONLY_Q=<q> instantiates ONE label count: tuning builds that compile in a
+// fraction of the time (sbm_bp_amd.build.build_variant; never the shipped library).
+#ifdef SBMBP_ONLY_Q
+#define DISPATCH_Q(Qv, ...)                                             \
+    switch (Qv) {                                                       \
+        case SBMBP_ONLY_Q: { constexpr int QQ = SBMBP_ONLY_Q; __VA_ARGS__; } break; \
+        default: set_error("this tuning build holds one label count only"); return SBMBP_ERR_UNSUPPORTED; \
+    }
+#else
 #define DISPATCH_Q(Qv, ...)                                             \
     switch (Qv) {                                                       \
         case 2: { constexpr int QQ = 2; __VA_ARGS__; } break;           \
@@ -193,6 +205,7 @@ inline int frame_rcap(uint32_t Q) { const int cap = frame_cap(Q); return cap / 2
         case 16: { constexpr int QQ = 16; __VA_ARGS__; } break;         \
         default: set_error("unsupported Q"); return SBMBP_ERR_UNSUPPORTED; \
     }
+#endif
 
 int upload_params(sbmbp_engine *e, double crit, bool hinted = false) {
     dev_params P;
@@ -311,10 +324,10 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form, bool f
     const double *psi_old = e->d_psi[pc];
     double *psi_new = e->d_psi[pc ^ 1];
     const int32_t *clamp = e->has_clamp ? e->d_clamp : nullptr;
-    // hub rows first, on their own stream: a few hundred long-running workgroups that overlap with the frame kernel
-    // (disjoint rows and edges; both only read psi_old and the parameter block)
     // Hub rows first, in fragments, on the sweep's own stream (disjoint rows and edges from the frame kernel's; they are
-    // throughput-bound like it: beside it on a second stream they gained nothing, C4 0.545 vs 0.533 ms per sweep).
+    // throughput-bound like it: beside it on a second stream they gained nothing, C4 0.545 vs 0.533 ms per sweep; round 3
+    // let the fragment PRODUCTS ride at the head of the frame launch instead of a launch of their own, and the frame kernel
+    // grew by exactly the product kernel's 0.037 ms: the fragments cost what their edges cost wherever they run).
     if (e->n_hub) {
         if (psi_form) CHK(launch_hub_psi(e, e->stream, 0, e->n_hub, Mnew, psi_old, psi_new, clamp, shard_io{}, Mold, int(first_from_psi)));
         else CHK(launch_hub_msg(e, e->stream, Mold, Mnew, psi_old, psi_new, clamp, damp));
@@ -503,6 +516,7 @@ int run_sweeps(sbmbp_engine *e, double crit, uint32_t max_sweeps, double damping
     if (executed > 0 && last != nullptr && !cs.last_exact) CHK(message_diff(e, &exact));
     e->sweeps += executed;
     e->psi_sweeps += psi_count;
+    if (executed > 0) e->fz.valid = false;
     const bool relaxed = cs.ar_fl > 0 || cs.ar_gl >= 0;
     const double damp_eff = damping * ar_gen_damp(cs.ar_gl);
     if (executed > 0) {
@@ -552,7 +566,82 @@ int refresh_field(sbmbp_engine *e) {
     return SBMBP_OK;
 }
 
+// the three Q x Q matrices of the non-edge term in d_mats: N(1 - (1-cab/N)^beta), (1-cab/N)^beta, cab   (bp.cpp:675-741)
+int upload_nonedge_mats(sbmbp_engine *e, std::vector<double> &mats, double *wmax_out) {
+    const uint32_t Q = e->Q, N = e->N;
+    mats.assign(3 * Q * Q, 0.0);
+    double *wmat = mats.data(), *Pmat = mats.data() + Q * Q, *cabm = mats.data() + 2 * Q * Q;
+    double wmax = 0.0;
+    for (uint32_t a = 0; a < Q * Q; ++a) {
+        Pmat[a] = std::pow(1.0 - e->cab[a] / double(N), e->beta);
+        wmat[a] = double(N) * (1.0 - Pmat[a]);
+        cabm[a] = e->cab[a];
+        wmax = std::max(wmax, std::max(wmat[a], cabm[a]));
+    }
+    HIPCHK(hipMemcpyAsync(e->d_mats, mats.data(), mats.size() * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (wmax_out) *wmax_out = wmax;
+    return SBMBP_OK;
+}
+inline bool nonedge_exact(const sbmbp_engine *e) { return (e->nonedge_mode == 1) || (e->nonedge_mode == 0 && e->N <= 32768); }
+
+// May the reductions take the fused pass on the marginal-gather reconstruction (k_fe_psi)? It needs exactly what the
+// marginal-gather SWEEP needs, and psi must be the marginals of the message pair in d_M: the state a converge call leaves.
+bool fused_ok(const sbmbp_engine *e) {
+    return e->fused_reductions && !e->sharded && e->psi_consistent && psi_form_allowed(e, 1.0);
+}
+
+// ONE pass: site / edge terms of free energy (and entropy), adjacent pairs of the non-edge term (dc 0), EM numerators.
+// Results stay in e->fz until the state changes.
+int fused_pass(sbmbp_engine *e, bool want_entropy, bool want_em) {
+    const uint32_t Q = e->Q;
+    want_em = want_em && Q <= 8;  // Q (Q+1) / 2 accumulators per lane: above Q = 8 the EM numerators keep their own kernel
+    if (e->fz.valid && (e->fz.entropy || !want_entropy) && (e->fz.em || !want_em)) return SBMBP_OK;
+    if (!e->field_fresh) { CHK(launch_field(e, 2)); e->field_fresh = true; }  // the site terms read h of the current marginals
+    int adj_mode = 0;
+    const double *d_w = nullptr;
+    if (e->dc == 0) {
+        std::vector<double> mats;
+        CHK(upload_nonedge_mats(e, mats, nullptr));
+        adj_mode = nonedge_exact(e) ? 2 : 1;
+        d_w = adj_mode == 2 ? e->d_mats + Q * Q : e->d_mats;
+    }
+    const uint32_t T = want_em ? Q * (Q + 1) / 2 : 0, NP = FE_NP + NE_NP + T, rows = e->n_blk + e->n_hub;
+    CHK(ensure_partials(e, size_t(std::max<uint32_t>(rows, 1)) * (NP + 1)));
+    CHK(ensure_small(e, NP));
+    const double *Mcur = e->d_M[e->cur], *Mprev = e->d_M[e->cur ^ 1], *psi = e->d_psi[e->pcur];
+    if (want_em) {
+        DISPATCH_Q(Q, hipLaunchKernelGGL((k_fe_psi<(QQ <= 8 ? QQ : 2), true>), dim3(xcd_grid(e->n_blk)), dim3(frame_cfg<(QQ <= 8 ? QQ : 2)>::TPB), 0, e->stream,
+                                         e->d_row_ptr, e->d_nbr, Mcur, Mprev, psi, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc),
+                                         int(want_entropy), adj_mode, d_w, e->n_blk, e->d_partials));
+    } else {
+        DISPATCH_Q(Q, hipLaunchKernelGGL((k_fe_psi<QQ, false>), dim3(xcd_grid(e->n_blk)), dim3(frame_cfg<QQ>::TPB), 0, e->stream,
+                                         e->d_row_ptr, e->d_nbr, Mcur, Mprev, psi, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc),
+                                         int(want_entropy), adj_mode, d_w, e->n_blk, e->d_partials));
+    }
+    if (e->n_hub)  // site and edge terms of the hub rows, in records of their own behind the segments'
+        DISPATCH_Q(Q, hipLaunchKernelGGL((k_fe_hub<QQ, false>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
+                                         e->d_rev, e->d_nbr, e->d_deg, Mcur, (const double *)nullptr, e->d_hub_row, e->d_hub_blk, e->d_P,
+                                         int(e->dc), int(want_entropy), e->d_partials, NP + 1, e->n_blk));
+    HIPCHK(hipGetLastError());
+    std::vector<double> out(NP);
+    CHK(fold_to_host(e, rows, NP, NP + 1, out.data()));
+    for (int x = 0; x < 4; ++x) e->fz.se[x] = out[x];
+    e->fz.adj[0] = out[FE_NP];
+    e->fz.adj[1] = out[FE_NP + 1];
+    e->fz.tri.assign(out.begin() + FE_NP + NE_NP, out.end());
+    e->fz.valid = true;
+    e->fz.entropy = want_entropy;
+    e->fz.em = want_em;
+    return SBMBP_OK;
+}
+
 int site_edge_terms(sbmbp_engine *e, bool want_entropy, double out[4], double *d_out = nullptr) {
+    if (d_out == nullptr && fused_ok(e)) {
+        CHK(fused_pass(e, want_entropy, false));
+        for (int x = 0; x < 4; ++x) out[x] = e->fz.se[x];
+        return SBMBP_OK;
+    }
     CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (FE_NP + 1)));
     const double *M = e->d_M[e->cur];
     const double *Min = (e->sharded && e->incoming_src == 0) ? e->d_Min : nullptr;
@@ -562,7 +651,7 @@ int site_edge_terms(sbmbp_engine *e, bool want_entropy, double out[4], double *d
         if (e->n_hub)
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_hub<QQ, true>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
                                                 e->d_rev, e->d_nbr, e->d_deg, M, Min, e->d_hub_row, e->d_hub_blk, e->d_P, 1,
-                                                int(want_entropy), e->d_partials));
+                                                int(want_entropy), e->d_partials, uint32_t(FE_NP + 1), 0xffffffffu));
     } else {
         DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_frame<QQ, false>), dim3(e->n_blk), dim3(frame_cfg<QQ>::TPB), 0, e->stream, e->d_row_ptr,
                                             e->d_rev, e->d_nbr, e->d_deg, M, Min, e->d_blk_row, e->d_blk_e0, e->d_P, int(e->dc), int(want_entropy),
@@ -570,7 +659,7 @@ int site_edge_terms(sbmbp_engine *e, bool want_entropy, double out[4], double *d
         if (e->n_hub)
             DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_fe_hub<QQ, false>), dim3(e->n_hub), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
                                                 e->d_rev, e->d_nbr, e->d_deg, M, Min, e->d_hub_row, e->d_hub_blk, e->d_P, int(e->dc),
-                                                int(want_entropy), e->d_partials));
+                                                int(want_entropy), e->d_partials, uint32_t(FE_NP + 1), 0xffffffffu));
     }
     HIPCHK(hipGetLastError());
     if (d_out) return fold_to_device(e, e->n_blk, FE_NP, FE_NP + 1, d_out);
@@ -627,20 +716,15 @@ int nonedge_terms(sbmbp_engine *e, bool want_entropy, double out[2]) {
     if (e->dc != 0) return SBMBP_OK;  // exactly 0 in the reference (:687-700, :721-727)
     const uint32_t Q = e->Q, N = e->N;
     const double invN = 1.0 / double(N);
-    std::vector<double> mats(3 * Q * Q);
-    double *wmat = mats.data(), *Pmat = mats.data() + Q * Q, *cabm = mats.data() + 2 * Q * Q;
+    std::vector<double> mats;
     double wmax = 0.0;
-    for (uint32_t a = 0; a < Q * Q; ++a) {
-        Pmat[a] = std::pow(1.0 - e->cab[a] / double(N), e->beta);
-        wmat[a] = double(N) * (1.0 - Pmat[a]);
-        cabm[a] = e->cab[a];
-        wmax = std::max(wmax, std::max(wmat[a], cabm[a]));
-    }
-    HIPCHK(hipMemcpyAsync(e->d_mats, mats.data(), mats.size() * 8, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    CHK(upload_nonedge_mats(e, mats, &wmax));
+    const double *wmat = mats.data(), *cabm = mats.data() + 2 * Q * Q;
     const double *d_w = e->d_mats, *d_Pm = e->d_mats + Q * Q, *d_cab = e->d_mats + 2 * Q * Q;
-    bool exact = (e->nonedge_mode == 1) || (e->nonedge_mode == 0 && N <= 32768);
+    const bool exact = nonedge_exact(e);
     double adj[2] = {0.0, 0.0}, all[2] = {0.0, 0.0};
+    const bool adj_known = fused_ok(e) && e->fz.valid && (e->fz.entropy || !want_entropy);  // the fused pass has the adjacent pairs already
+    if (adj_known) { adj[0] = e->fz.adj[0]; adj[1] = e->fz.adj[1]; }
     if (exact) {
         const uint32_t g = (N + BLOCK - 1) / BLOCK;
         CHK(ensure_partials(e, size_t(g) * g * (NE_NP + 1)));
@@ -648,12 +732,14 @@ int nonedge_terms(sbmbp_engine *e, bool want_entropy, double out[2]) {
                                          e->d_psi[e->pcur], N, d_Pm, d_cab, invN, int(want_entropy), e->d_partials));
         HIPCHK(hipGetLastError());
         CHK(fold_to_host(e, g * g, NE_NP, NE_NP + 1, all));
+        if (!adj_known) {
         CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (NE_NP + 1)));
         DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_exact_adj<QQ>), dim3(e->n_blk), dim3(frame_cfg<QQ>::TPB), 0, e->stream, e->d_row_ptr,
                                          e->d_nbr, e->d_psi[e->pcur], d_Pm, d_cab, e->d_blk_row, invN, int(want_entropy),
                                          e->d_partials));
         HIPCHK(hipGetLastError());
         CHK(fold_to_host(e, e->n_blk, NE_NP, NE_NP + 1, adj));
+        }
     } else {
         const int K = choose_series_order(e, wmax);
         const int Kent = want_entropy ? K : 0;  // entropy term k uses M_{k+1}: orders 1..K as well
@@ -686,11 +772,13 @@ int nonedge_terms(sbmbp_engine *e, bool want_entropy, double out[2]) {
             }
             off += tsz;
         }
+        if (!adj_known) {
         CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (NE_NP + 1)));
         DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_adj<QQ>), dim3(e->n_blk), dim3(frame_cfg<QQ>::TPB), 0, e->stream, e->d_row_ptr,
                                          e->d_nbr, e->d_psi[e->pcur], d_w, d_cab, e->d_blk_row, invN, int(want_entropy), e->d_partials));
         HIPCHK(hipGetLastError());
         CHK(fold_to_host(e, e->n_blk, NE_NP, NE_NP + 1, adj));
+        }
     }
     out[0] = (all[0] - adj[0]) / (2.0 * N);
     out[1] = (all[1] - adj[1]) / (2.0 * N);
@@ -721,6 +809,12 @@ int em_expect(sbmbp_engine *e, double *na_e, double *nna_e, double *cab_e) {
     CHK(row_sums(e, rs));
     const double *na = rs.data(), *nna = rs.data() + Q;
     const uint32_t T = Q * (Q + 1) / 2;
+    std::vector<double> tri(T);
+    if (fused_ok(e) && Q <= 8) {
+        // the numerators come out of the fused pass, which also leaves the free-energy terms the EM loop asks for next
+        CHK(fused_pass(e, false, true));
+        tri = e->fz.tri;
+    } else {
     const uint32_t nb = uint32_t(std::min<uint64_t>(2048, std::max<uint64_t>(1, (e->E2 + BLOCK - 1) / BLOCK)));
     CHK(ensure_partials(e, size_t(nb) * (T + 1)));
     // k_em_edges reads cab/invN from the parameter block, which is in sync with the host mirror here:
@@ -735,8 +829,8 @@ int em_expect(sbmbp_engine *e, double *na_e, double *nna_e, double *cab_e) {
                                          e->d_nbr, e->d_deg, e->d_src, M, Min, uint32_t(e->E2), e->d_P, e->d_partials));
     }
     HIPCHK(hipGetLastError());
-    std::vector<double> tri(T);
     CHK(fold_to_host(e, nb, T, T + 1, tri.data()));
+    }
     std::vector<double> ce(Q * Q, 0.0);
     uint32_t t = 0;
     for (uint32_t q1 = 0; q1 < Q; ++q1)
@@ -824,7 +918,7 @@ void apply_params_host(sbmbp_engine *e, const double *cab, const uint32_t *na, d
     e->beta = beta;
     e->have_params = true;
     e->field_fresh = false;
-    e->psi_consistent = false;  // the reconstruction psi / (W^T m) needs the W the marginals were formed with
+    e->psi_consistent = false; e->fz.valid = false;  // the reconstruction psi / (W^T m) needs the W the marginals were formed with
     e->w_positive = true;
     for (uint32_t a = 0; a < Q * Q; ++a)
         if (!(cab[a] > 0.0) || !(cab[a] < 1e300)) e->w_positive = false;
@@ -973,6 +1067,7 @@ int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint3
     TRY(dev_alloc(e, &e->d_psi[1], size_t(e->N) * Q));
     TRY(dev_alloc(e, &e->d_P, 1));
     TRY(dev_alloc(e, &e->d_mats, 3 * Q * Q));
+    if (const char *fr = std::getenv("SBMBP_FUSED_REDUCTIONS")) e->fused_reductions = std::atoi(fr);
     e->hist_cap = 4096;
     TRY(dev_alloc(e, &e->d_hist, e->hist_cap));
     TRY(ensure_partials(e, size_t(e->n_blk) * (QMAX + 1)));
@@ -1124,7 +1219,7 @@ int sbmbp_init_messages(sbmbp_engine_t *e, uint32_t flag, const int32_t *conf, c
     HIPCHK(hipStreamSynchronize(e->stream));
     e->have_state = true;
     e->field_fresh = false;
-    e->psi_consistent = false;
+    e->psi_consistent = false; e->fz.valid = false;
     e->init_from_psi = false;
     e->clamp_onehot = (flag == 1 || flag == 3);  // clamped rows now hold one-hot marginals and messages
     return SBMBP_OK;
@@ -1155,7 +1250,7 @@ int sbmbp_init_messages_device(sbmbp_engine_t *e, uint64_t seed, const uint32_t 
     HIPCHK(hipStreamSynchronize(e->stream));
     e->have_state = true;
     e->field_fresh = false;
-    e->psi_consistent = false;
+    e->psi_consistent = false; e->fz.valid = false;
     e->init_from_psi = true;
     e->clamp_onehot = false;
     return SBMBP_OK;
@@ -1227,7 +1322,7 @@ int sbmbp_set_state(sbmbp_engine_t *e, const double *psi, const double *msg_out)
     HIPCHK(hipStreamSynchronize(e->stream));
     if (psi && (msg_out || e->E2 == 0)) e->have_state = true;  // a graph without edges has no messages
     e->field_fresh = false;
-    e->psi_consistent = false;
+    e->psi_consistent = false; e->fz.valid = false;
     e->init_from_psi = false;
     e->clamp_onehot = false;  // an arbitrary state: clamped rows need the general (message-gather) sweep
     return SBMBP_OK;

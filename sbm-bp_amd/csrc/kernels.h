@@ -351,11 +351,11 @@ template <int NS, int NW = 4> __device__ __forceinline__ void block_reduce_store
 
 // exact power-of-two rescale of a Q-vector so that its largest entry has exponent 0; returns the
 // removed exponent (0 when no rescale was needed)
-template <int Q> __device__ __forceinline__ int rescale_pow2(double (&A)[Q]) {
+template <int Q> __device__ __forceinline__ int rescale_pow2(double (&A)[Q], double lo = 1e-100, double hi = 1e100) {
     double amax = A[0];
 #pragma unroll
     for (int q = 1; q < Q; ++q) amax = fmax(amax, A[q]);
-    if (amax > 1e-100 && amax < 1e100) return 0;
+    if (amax > lo && amax < hi) return 0;
     if (!(amax > 0.0) || amax > 1.7e308) return 0;  // zero, NaN or Inf: nothing sensible to do
     int n = ilogb(amax);
 #pragma unroll
@@ -492,7 +492,10 @@ template <int Q> __device__ __forceinline__ void block_product_x(double (&A)[Q],
 // butterfly multiplies the 64 partial products (every lane ends with the same value: a*b == b*a
 // bitwise, so the result is deterministic). Used for rows above BIG_ROW edges, where the lane-per-row
 // loop would serialise hundreds of LDS reads while the rest of the workgroup waits.
-constexpr int BIG_ROW = 32;
+#ifndef SBMBP_BIG_ROW
+#define SBMBP_BIG_ROW 32
+#endif
+constexpr int BIG_ROW = SBMBP_BIG_ROW;
 template <int Q> __device__ __forceinline__ void row_product_wave(const double *sb, int es, int ee, double (&A)[Q], int (&ae)[Q]) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -532,6 +535,33 @@ template <int Q> __device__ __forceinline__ void recip_all(const double (&x)[Q],
 #pragma unroll
     for (int k = Q - 1; k > 0; --k) { r[k] = inv * p[k - 1]; inv *= x[k]; }
     r[0] = inv;
+}
+
+#ifndef SBMBP_NODIV
+#define SBMBP_NODIV 1  // 1: division-free reconstruction and cavity in the marginal-gather sweep (one division per edge instead of four)
+#endif
+// r[k] = prod_{j != k} x[j] from prefix and suffix products (3 (Q-1) multiplications, no division): x[k] r[k] is the same
+// for every k, so r is 1 / x up to ONE common factor - and every place the marginal-gather sweep divides by a Q-vector
+// normalises the result right after. Returns false when the product of all x leaves the normal range (the caller divides).
+template <int Q> __device__ __forceinline__ bool excl_products(const double (&x)[Q], double (&r)[Q]) {
+    double pre = x[0];
+    r[0] = 1.0;
+#pragma unroll
+    for (int k = 1; k < Q; ++k) { r[k] = pre; pre *= x[k]; }
+    double suf = x[Q - 1];
+#pragma unroll
+    for (int k = Q - 2; k >= 0; --k) { r[k] *= suf; suf *= x[k]; }
+    return pre > 1e-250 && pre < 1e250;
+}
+// v <- v 2^-e with e the binary exponent of the sum of v (an exact scaling): the vector then sums to [0.5, 1)
+template <int Q> __device__ __forceinline__ void pow2_normalise(double (&v)[Q]) {
+    double t = v[0];
+#pragma unroll
+    for (int k = 1; k < Q; ++k) t += v[k];
+    int e;
+    (void)frexp(t, &e);  // 0, NaN, Inf: e = 0 (nothing sensible to scale)
+#pragma unroll
+    for (int k = 0; k < Q; ++k) v[k] = ldexp(v[k], -e);
 }
 
 // b[q] = sum_t W_il[t][q] m[t]   (belief_propagation.cpp:1000-1012)
@@ -973,6 +1003,40 @@ template <int Q> __device__ __forceinline__ void send_row(const shard_io &io, ui
     }
 }
 
+// product of the workgroup's per-lane partial products, every lane returning the result: shuffle butterfly inside
+// the waves (both partners of a step compute the same bits: a*b == b*a), then the wave results in wave order
+template <int Q, int WAVES> __device__ __forceinline__ void block_product_shfl(double (&A)[Q], int (&ae)[Q], double *sAw, int *sEw) {
+    x_norm<Q>(A, ae);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { A[q] *= __shfl_xor(A[q], o, 64); ae[q] += __shfl_xor(ae[q], o, 64); }
+        x_norm<Q>(A, ae);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { sAw[wave * Q + q] = A[q]; sEw[wave * Q + q] = ae[q]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { A[q] = sAw[q]; ae[q] = sEw[q]; }
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { A[q] *= sAw[w * Q + q]; ae[q] += sEw[w * Q + q]; }
+        x_norm<Q>(A, ae);
+    }
+}
+
+// fragment tables of the hub rows (rows above one segment's edge capacity), see k_hub_frag_product below
+struct hub_frags {
+    const uint32_t *frag_hub;   // [n_frag] hub index of the fragment
+    const uint32_t *hub_frag0;  // [n_hub + 1] first fragment of the hub
+    double *b;                  // [n_frag * BLOCK][Q] edge fields between the two launches
+    double *pA;                 // [n_frag][Q] fragment products: mantissas ...
+    int *pE;                    // ... and binary exponents
+};
 // CLAMP: rows with clamp[i] != -1 (bp_conditional, bp.cpp:1100-1126) keep their marginal and out-messages. Their state is
 // one-hot (-i 1 / -f), and for a one-hot neighbour the reconstruction psi_l / (W^T m) normalises to that same one-hot
 // vector exactly, so clamped rows need no special case on the receiving side.
@@ -1064,6 +1128,9 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
 #endif
             const bool full = !halo || io.ncomp == Q;
             const double *src = halo ? io.halo_stage + size_t(nl[j] - io.n_own) * io.ncomp : psi_old + size_t(nl[j]) * Q;
+            // (Round 3 tried the same Q/2 16-byte loads for both kinds of row, a received row read one double past its end and
+            // that slot restored afterwards: 0.367 against 0.363 ms per rank of the 8-rank C3 plan - the load width is not what
+            // the shard variant pays for.)
 #pragma unroll
             for (int q = 0; q < Q - 1; ++q) pl[j][q] = src[q];
             const double lastv = src[full ? Q - 1 : 0];
@@ -1103,19 +1170,31 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
                 for (int s = 0; s < Q; ++s) inc[s] = pl[j][s];
             } else {
                 edge_field<Q, false>(P, mo[j], 0.0, bo);  // what l saw of i's message at sweep t-1
-                double tot = 0.0;
-#if SBMBP_BATCH_RECIP
+#if SBMBP_NODIV
+                // m^t_{l->i} up to a factor: psi_l[s] prod_{s' != s} bo[s'], scaled by an exact power of two. The factor ends
+                // up in b, in the row product and in every cavity of the row alike, and cancels in their normalisations.
                 double rb[Q];
-                recip_all<Q>(bo, rb);
+                if (excl_products<Q>(bo, rb)) {
 #pragma unroll
-                for (int s = 0; s < Q; ++s) { inc[s] = pl[j][s] * rb[s]; tot += inc[s]; }
+                    for (int s = 0; s < Q; ++s) inc[s] = pl[j][s] * rb[s];
+                    pow2_normalise<Q>(inc);
+                } else
+#endif
+                {
+                    double tot = 0.0;
+#if SBMBP_BATCH_RECIP
+                    double rr[Q];
+                    recip_all<Q>(bo, rr);
+#pragma unroll
+                    for (int s = 0; s < Q; ++s) { inc[s] = pl[j][s] * rr[s]; tot += inc[s]; }
 #else
 #pragma unroll
-                for (int s = 0; s < Q; ++s) { inc[s] = pl[j][s] / bo[s]; tot += inc[s]; }
+                    for (int s = 0; s < Q; ++s) { inc[s] = pl[j][s] / bo[s]; tot += inc[s]; }
 #endif
-                const double inv = 1.0 / tot;
+                    const double inv = 1.0 / tot;
 #pragma unroll
-                for (int s = 0; s < Q; ++s) inc[s] *= inv;  // m^t_{l->i}
+                    for (int s = 0; s < Q; ++s) inc[s] *= inv;  // m^t_{l->i}
+                }
             }
             edge_field<Q, false>(P, inc, 0.0, b);
             store_vec<Q>(&sb[le * Q], b);
@@ -1178,6 +1257,9 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
             if (tab) load_vec<Q>(P->ftab + size_t(ee - es) * QMAX, ft);
 #pragma unroll
             for (int q = 0; q < Q; ++q) A[q] = 1.0;
+            // (Round 3 measured two variants of this loop on C4 / the Q = 8 control / C3 and dropped both: the next factor
+            // loaded before the current one is multiplied in, with the rescale every fourth factor: +1.5 % kernel time
+            // everywhere; BIG_ROW = 64 / 128 / 256, i.e. fewer or no wave products: C4 +0.3 / +5 / +12 %.)
             for (int e = es; e < ee; ++e) {
                 double b[Q];
                 load_vec<Q>(&sb[e * Q], b);
@@ -1221,15 +1303,20 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
             load_vec<Q>(&sA[r * Q], A);
             load_vec<Q>(&sb[le * Q], b);
             double tot = 0.0;
-#if SBMBP_BATCH_RECIP
             double rb[Q];
-            recip_all<Q>(b, rb);
-#pragma unroll
-            for (int q = 0; q < Q; ++q) { cav[q] = A[q] * rb[q]; tot += cav[q]; }
+#if SBMBP_NODIV
+            if (!excl_products<Q>(b, rb))  // cavity up to a factor: A[q] prod_{q' != q} b[q'] (the one division left is 1 / tot)
+#endif
+            {
+#if SBMBP_BATCH_RECIP
+                recip_all<Q>(b, rb);
 #else
 #pragma unroll
-            for (int q = 0; q < Q; ++q) { cav[q] = A[q] / b[q]; tot += cav[q]; }
+                for (int q = 0; q < Q; ++q) rb[q] = 1.0 / b[q];
 #endif
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { cav[q] = A[q] * rb[q]; tot += cav[q]; }
             const double inv = 1.0 / tot;
             double ref[Q];
             if (exact) {  // uniform
@@ -1249,32 +1336,6 @@ k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ n
     block_reduce_store<Q, frame_cfg<Q>::WAVES>(Sacc, md, sred, partials + size_t(bid) * (Q + 1));
 }
 
-// product of the workgroup's per-lane partial products, every lane returning the result: shuffle butterfly inside
-// the waves (both partners of a step compute the same bits: a*b == b*a), then the wave results in wave order
-template <int Q, int WAVES> __device__ __forceinline__ void block_product_shfl(double (&A)[Q], int (&ae)[Q], double *sAw, int *sEw) {
-    x_norm<Q>(A, ae);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-        for (int q = 0; q < Q; ++q) { A[q] *= __shfl_xor(A[q], o, 64); ae[q] += __shfl_xor(ae[q], o, 64); }
-        x_norm<Q>(A, ae);
-    }
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int q = 0; q < Q; ++q) { sAw[wave * Q + q] = A[q]; sEw[wave * Q + q] = ae[q]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < Q; ++q) { A[q] = sAw[q]; ae[q] = sEw[q]; }
-#pragma unroll
-    for (int w = 1; w < WAVES; ++w) {
-#pragma unroll
-        for (int q = 0; q < Q; ++q) { A[q] *= sAw[w * Q + q]; ae[q] += sEw[w * Q + q]; }
-        x_norm<Q>(A, ae);
-    }
-}
-
 // K1ph: marginal-gather form of the hub-row update (rows with degree > CAP), in FRAGMENTS of BLOCK edges.
 // One workgroup per hub row is a latency chain as long as the row (neighbour index -> its marginal, per 256 edges, twice),
 // the sweep waits for the longest row, and a degree-1e5 hub of a large power-law graph would run for milliseconds: measured
@@ -1285,13 +1346,6 @@ template <int Q, int WAVES> __device__ __forceinline__ void block_product_shfl(d
 // Every workgroup of a row multiplies the same fragment products in the same order, so they agree bitwise on the row
 // product. The maximum message difference of the fragments meets in the row's partial record through atomicMax on the bit
 // pattern (differences are >= 0 or NaN, and a NaN pattern is above every number: order-independent, so reproducible).
-struct hub_frags {
-    const uint32_t *frag_hub;   // [n_frag] hub index of the fragment
-    const uint32_t *hub_frag0;  // [n_hub + 1] first fragment of the hub
-    double *b;                  // [n_frag * BLOCK][Q] edge fields between the two launches
-    double *pA;                 // [n_frag][Q] fragment products: mantissas ...
-    int *pE;                    // ... and binary exponents
-};
 template <int Q>
 __global__ void __launch_bounds__(BLOCK)
 k_hub_frag_product(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, const double *__restrict__ Mio,
@@ -1841,12 +1895,224 @@ k_fe_frame(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ re
     block_reduce_store<FE_NP, frame_cfg<Q>::WAVES>(acc, 0.0, sred, partials + size_t(blockIdx.x) * (FE_NP + 1));
 }
 
+// ------------------------------------------------------------------------------------------------
+// K3p: the reductions of one inference / EM step in ONE pass, on the marginal-gather reconstruction (single engine, dc 0/1,
+// every cab entry > 0, psi consistent with the two message buffers: exactly the state a converge call leaves behind).
+// k_fe_frame / k_em_edges gather the incoming message M[rev[k]]: a 8(Q-1)-byte record out of the whole message array (2.4 GB
+// at C3), one or two 64-byte fabric requests each, once per kernel. Here it is reconstructed as in k_sweep_psi,
+//     m^T_{l->i}  ∝  psi^T_l / (W^T m^{T-1}_{i->l}),
+// from the neighbour's marginal (the N*Q table, 1/c the size, cache resident with the XCD-aware numbering) and the row's own
+// previous record (streamed), and everything that needs (m_in, m_out) of an edge or psi_l is formed while it is in registers:
+//   FE_NP  site and edge terms of the free energy and the entropy              (k_fe_frame)
+//   NE_NP  the adjacent pairs of the non-edge term, which gather psi_l too     (k_nonedge_adj / k_nonedge_exact_adj; dc 0)
+//   EM     the Q(Q+1)/2 numerators of cab_expect                               (k_em_edges; template EM, Q <= 8)
+// Record layout: [FE_NP | NE_NP | T] sums then one unused max slot. Hub rows (above one segment's capacity): their site and
+// edge terms come from k_fe_hub (records behind the segments'); this kernel adds their adjacent-pair and EM terms.
+// ------------------------------------------------------------------------------------------------
+constexpr int NE_NP = 2;
+template <int Q, bool EM> struct fe_psi_cfg {
+    static constexpr int T = EM ? Q * (Q + 1) / 2 : 0;
+    static constexpr int NP = FE_NP + NE_NP + T;
+};
+template <int Q, bool EM>
+__global__ void __launch_bounds__(frame_cfg<Q>::TPB)
+k_fe_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, const double *__restrict__ Mcur /* m^T */,
+         const double *__restrict__ Mprev /* m^{T-1} */, const double *__restrict__ psi /* psi^T */,
+         const uint32_t *__restrict__ blk_row, const uint32_t *__restrict__ blk_e0, const dev_params *__restrict__ P, int dc,
+         int want_entropy, int adj_mode /* 0: no non-edge term (dc != 0), 1: series weights (wmat), 2: exact (pmat) */,
+         const double *__restrict__ wmat /* mode 1: N(1-(1-cab/N)^beta); mode 2: (1-cab/N)^beta */, uint32_t n_seg,
+         double *__restrict__ partials) {
+    constexpr int EPT = frame_cfg<Q>::EPT, CAP = frame_cfg<Q>::CAP, RCAP = frame_cfg<Q>::RCAP, TPB = frame_cfg<Q>::TPB;
+    constexpr int T = fe_psi_cfg<Q, EM>::T, NP = fe_psi_cfg<Q, EM>::NP;
+    __shared__ double sb[CAP * Q];
+    __shared__ double sc[CAP * Q];  // entropy: b with plain cab weights (no beta)
+    __shared__ uint32_t srp[RCAP + 1];
+    __shared__ uint16_t srow[CAP];
+    __shared__ double sred[frame_cfg<Q>::WAVES * (NP + 1)];
+    __shared__ double sclc[Q * Q];  // cab log cab (entropy of the adjacent pairs)
+    const int tid = threadIdx.x;
+#if SBMBP_XCD_REMAP
+    const uint32_t per = gridDim.x / 8;  // grid padded by xcd_grid: XCD x takes the contiguous segments [x per, (x+1) per)
+    const uint32_t bid = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (bid >= n_seg) return;
+#else
+    const uint32_t bid = blockIdx.x;
+#endif
+    const uint32_t r0 = blk_row[bid], r1 = blk_row[bid + 1];
+    const int nrows = int(r1 - r0);
+    const uint32_t e0 = blk_e0[bid];
+    const int ne = int(blk_e0[bid + 1] - e0);
+    const double invN = P->invN;
+    double acc[NP];
+#pragma unroll
+    for (int x = 0; x < NP; ++x) acc[x] = 0.0;
+    if (want_entropy && adj_mode)
+        for (int x = tid; x < Q * Q; x += TPB) sclc[x] = P->cab[x] * P->logcab[x];
+
+    // everything of one directed edge that needs its two messages or the neighbour's marginal; `site`: also b (and c) to LDS
+    auto edge = [&](uint32_t k, int le, const double (&mo)[Q], const double (&mp)[Q], const double (&pl)[Q], const double *pi, bool site) {
+        double bo[Q], mi[Q], rb[Q];
+        edge_field<Q, false>(P, mp, 0.0, bo);  // what l saw of i's message at T-1
+        double tot = 0.0;
+        if (!excl_products<Q>(bo, rb)) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) rb[q] = 1.0 / bo[q];
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { mi[q] = pl[q] * rb[q]; tot += mi[q]; }
+        const double inv = 1.0 / tot;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) mi[q] *= inv;  // m^T_{l->i}
+        if (site) {
+            double b[Q];
+            edge_field<Q, false>(P, mi, 0.0, b);
+            store_vec<Q>(&sb[le * Q], b);
+            if (want_entropy) {
+                double c[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int t = 0; t < Q; ++t) a += P->cab[t * Q + q] * mi[t];
+                    c[q] = a;
+                }
+                store_vec<Q>(&sc[le * Q], c);
+            }
+            double ln, en;
+            edge_terms<Q, false>(P, mi, mo, 0.0, want_entropy, ln, en);
+            acc[1] += ln;
+            if (want_entropy) acc[3] += en;
+        }
+        if (adj_mode) {  // adjacent pairs of the non-edge term (bp.cpp:675-741 sums over NON-adjacent pairs: these are taken out)
+            double y = 0.0, yc = 0.0, u = 0.0;
+#pragma unroll
+            for (int q1 = 0; q1 < Q; ++q1) {
+#pragma unroll
+                for (int q2 = 0; q2 < Q; ++q2) {
+                    const double pp = pi[q1] * pl[q2];
+                    y += wmat[q1 * Q + q2] * pp;
+                    if (want_entropy) {
+                        yc += P->cab[q1 * Q + q2] * pp;
+                        u += sclc[q1 * Q + q2] * pp;
+                    }
+                }
+            }
+            const double num = u * invN, den = 1.0 - yc * invN;
+            if (adj_mode == 1) {  // series form (k_nonedge_adj): y = sum N (1 - (1 - cab/N)^beta) pp
+                acc[FE_NP + 0] += log1p(-y * invN);
+                if (want_entropy) acc[FE_NP + 1] += num / den;
+            } else {              // exact form (k_nonedge_exact_adj): y = sum (1 - cab/N)^beta pp, with the tiled kernel's guards
+                if (y != 0.0) acc[FE_NP + 0] += log(y);
+                if (want_entropy && num * den != 0.0) acc[FE_NP + 1] += num / den;
+            }
+        }
+        if (EM) {  // numerators of cab_expect (bp.cpp:892-989)
+            double term[T > 0 ? T : 1], norm_L = 0.0;
+            int t = 0;
+#pragma unroll
+            for (int q1 = 0; q1 < Q; ++q1) {
+#pragma unroll
+                for (int q2 = q1; q2 < Q; ++q2, ++t) {
+                    const double pr = (q1 == q2) ? (mi[q1] * mo[q2]) : (mi[q1] * mo[q2] + mi[q2] * mo[q1]);
+                    term[t] = P->cab[q1 * Q + q2] * pr;
+                    norm_L += term[t];
+                }
+            }
+            const double hin = 0.5 / norm_L;
+#pragma unroll
+            for (int x = 0; x < T; ++x) acc[FE_NP + NE_NP + x] += term[x] * hin;
+        }
+        (void)k;
+    };
+
+    if (ne <= CAP) {
+        constexpr int RPT = RCAP / TPB + 1;
+        uint32_t kk[EPT], nl[EPT], rpv[RPT];
+        double mo_[EPT][Q], mp_[EPT][Q], pl_[EPT][Q];
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int le = j * TPB + tid;
+            kk[j] = (ne > 0) ? e0 + uint32_t(le < ne ? le : 0) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) nl[j] = nbr[kk[j]];
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) load_msg<Q>(Mcur, size_t(kk[j]), mo_[j]);
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) load_msg<Q>(Mprev, size_t(kk[j]), mp_[j]);
+#pragma unroll
+        for (int t = 0; t < RPT; ++t) { const int r = tid + t * TPB; rpv[t] = row_ptr[r0 + uint32_t(r < nrows ? r : nrows)]; }
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) load_vec<Q>(psi + size_t(nl[j]) * Q, pl_[j]);
+#pragma unroll
+        for (int t = 0; t < RPT; ++t) { const int r = tid + t * TPB; if (r <= nrows) srp[r] = rpv[t] - e0; }
+        __syncthreads();
+        if (adj_mode) {  // the adjacent pairs need the row of every edge (its own marginal)
+            for (int r = tid; r < nrows; r += TPB)
+                for (int e = int(srp[r]); e < int(srp[r + 1]); ++e) srow[e] = uint16_t(r);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int le = j * TPB + tid;
+            if (le < ne) {
+                double pi[Q];
+                if (adj_mode) load_vec<Q>(psi + size_t(r0 + srow[le]) * Q, pi);
+                edge(kk[j], le, mo_[j], mp_[j], pl_[j], pi, true);
+            }
+        }
+        __syncthreads();
+        for (int r = tid; r < nrows; r += TPB) {
+            const int es = int(srp[r]), ee = int(srp[r + 1]);
+            const double di = double(ee - es);
+            double A[Q];
+            int ae[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { A[q] = 1.0; ae[q] = 0; }
+            for (int e = es; e < ee; ++e) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) A[q] *= sb[e * Q + q];
+                if (((e - es) & 7) == 7) x_norm<Q>(A, ae);  // eight factors of O(W) stay far inside the double range
+            }
+            x_norm<Q>(A, ae);
+            acc[0] += log_partition_x<Q>(P, dc, di, A, ae);  // log Z_i  (bp.cpp:446-502)
+            if (want_entropy) {  // e_site (bp.cpp:506-560): no beta, weights exp(a + log eta - h/N)
+                double C[Q];
+                int ce[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) { C[q] = 1.0; ce[q] = 0; }
+                for (int e = es; e < ee; ++e) {
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) C[q] *= sc[e * Q + q];
+                    if (((e - es) & 7) == 7) x_norm<Q>(C, ce);
+                }
+                x_norm<Q>(C, ce);
+                acc[2] += entropy_site_x<Q>(P, C, ce);
+            }
+        }
+    } else if (adj_mode || EM) {  // a hub row (its site and edge terms: k_fe_hub): adjacent pairs and EM numerators, lanes strided over its edges
+        double pi[Q];
+        if (adj_mode) load_vec<Q>(psi + size_t(r0) * Q, pi);
+        __syncthreads();  // sclc
+        for (int le = tid; le < ne; le += TPB) {
+            const uint32_t k = e0 + uint32_t(le);
+            double mo[Q], mp[Q], pl[Q];
+            load_msg<Q>(Mcur, size_t(k), mo);
+            load_msg<Q>(Mprev, size_t(k), mp);
+            load_vec<Q>(psi + size_t(nbr[k]) * Q, pl);
+            edge(k, 0, mo, mp, pl, pi, false);
+        }
+    }
+    block_reduce_store<NP, frame_cfg<Q>::WAVES>(acc, 0.0, sred, partials + size_t(bid) * (NP + 1));
+}
+
 template <int Q, bool DC2>
 __global__ void __launch_bounds__(BLOCK)
 k_fe_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr, const uint32_t *__restrict__ ndeg /* degree of every table row (DC2 only) */,
          const double *__restrict__ M, const double *__restrict__ Min, const uint32_t *__restrict__ hub_row,
          const uint32_t *__restrict__ hub_blk, const dev_params *__restrict__ P, int dc, int want_entropy,
-         double *__restrict__ partials) {
+         double *__restrict__ partials, uint32_t rec_stride /* doubles per record (>= FE_NP + 1) */,
+         uint32_t rec_first /* record of hub 0, or 0xffffffff: the hub's own segment record hub_blk[h] */) {
     __shared__ double sAq[BLOCK * Q];
     __shared__ double sCq[BLOCK * Q];
     __shared__ int sEq[BLOCK * Q];
@@ -1894,7 +2160,9 @@ k_fe_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev,
         acc[0] += log_partition_x<Q>(P, dc, di, A, ae);
         if (want_entropy) acc[2] += entropy_site_x<Q>(P, C, ce);
     }
-    block_reduce_store<FE_NP>(acc, 0.0, sred, partials + size_t(hub_blk[blockIdx.x]) * (FE_NP + 1));
+    double *rec = partials + size_t(rec_first == 0xffffffffu ? hub_blk[blockIdx.x] : rec_first + blockIdx.x) * rec_stride;
+    block_reduce_store<FE_NP>(acc, 0.0, sred, rec);
+    for (uint32_t x = FE_NP + 1 + tid; x < rec_stride; x += BLOCK) rec[x] = 0.0;  // the other columns of a wider record (k_fe_psi)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1904,7 +2172,6 @@ k_fe_hub(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev,
 // One wave-friendly row loop: lane per row chunk, rows strided; gathers psi_l (N*Q table, cache
 // resident for the sizes where it matters).
 // ------------------------------------------------------------------------------------------------
-constexpr int NE_NP = 2;
 template <int Q>
 __global__ void __launch_bounds__(frame_cfg<Q>::TPB)
 k_nonedge_adj(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, const double *__restrict__ psi,

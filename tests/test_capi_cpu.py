@@ -217,3 +217,25 @@ def test_communicator_handles_and_no_device_errors():
     lib.sbmbp_comm_destroy(h)
     for r in range(3):
         lib.sbmbp_comm_destroy(arr[r])
+
+
+def test_host_code_under_asan_ubsan(tmp_path):
+    """the host side of the engine (csrc/host_graph.cpp) and the CPU restatement (oracle/bp_oracle.cpp)
+    compiled with -fsanitize=address,undefined and driven through their edge cases by tests/sanitize/host_sanitize.cpp (ragged
+    and missing edge lists, duplicates / self-loops / ids at the bound, every init flag against the oracle bit for bit - also
+    through the streaming sink -, both schedules, reductions, learning, a row of 699 edges). CPU build only: GPU
+    AddressSanitizer is not available on this pool."""
+    import shutil
+    import subprocess
+    from conftest import ROOT, gpath
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = tmp_path / "host_sanitize"
+    src = [os.path.join(ROOT, "tests", "sanitize", "host_sanitize.cpp"), os.path.join(ROOT, "sbm-bp_amd", "csrc", "host_graph.cpp"),
+           os.path.join(ROOT, "oracle", "bp_oracle.cpp")]
+    subprocess.run(["g++", "-std=c++14", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-mavx2", "-pthread",
+                    "-o", str(exe)] + src, check=True, timeout=600)
+    pr = subprocess.run([str(exe), gpath("c1_dataset.edgelist")], capture_output=True, text=True, timeout=600,
+                        env=dict(os.environ, TMPDIR=str(tmp_path), UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1"))
+    assert pr.returncode == 0 and "host_sanitize ok" in pr.stdout, (pr.stdout[-500:], pr.stderr[-3000:])
+    assert "runtime error" not in pr.stderr and "AddressSanitizer" not in pr.stderr and "LeakSanitizer" not in pr.stderr

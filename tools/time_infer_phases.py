@@ -9,6 +9,8 @@ from sbm_bp_amd import synth
 from bench import WORKLOADS
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
+if len(sys.argv) > 2:  # "separate": the round-2 kernels (k_fe_frame, k_nonedge_adj, k_em_edges) instead of the fused pass
+    os.environ["SBMBP_FUSED_REDUCTIONS"] = "0" if sys.argv[2] == "separate" else "1"
 N, Q, c, eps, dc, gseed = WORKLOADS[wl]
 S.load_library()
 if wl == "C4":
@@ -24,7 +26,7 @@ bp.init_messages_device(bm, synth.true_conf(N, Q), 1234)
 bp.expand_bp_params(S.bp_blockmodel_state(cab, np.array(synth.group_sizes(N, Q), dtype=np.uint32)))
 
 
-def timed(f, reps=3):
+def timed(f, reps=1):  # (one repetition: the fused reduction pass keeps its results until the state changes)
     out = None
     best = 1e9
     for _ in range(reps):
