@@ -137,20 +137,29 @@ def pmc_traffic(workload, kernel, n_gpus, E2, N, Q):
         return None, None
     sha = source_sha()
     stale = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json")), reverse=True):
+    stream_reads = E2 * (8.0 * (Q - 1) + 4.0) + N * 4.0  # own old message record (Q-1 components) + index per edge, row offsets
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc*.json")), reverse=True):
         try:
             d = json.load(open(path))
         except Exception:
             continue
-        if d.get("kernel") == kernel and d.get("workload", "").startswith(workload + " "):
-            if d.get("source_sha") != sha:
-                stale = stale or "%s was collected on kernel sources %s, this build is %s" % (
-                    os.path.relpath(path, ROOT), d.get("source_sha", "(unrecorded)"), sha)
+        c = None
+        if "kernels" in d:  # tools/pmc_workload.sh (round 3 on): one file per workload, every sweep-path kernel in it
+            if d.get("workload") != workload:
                 continue
+            for k, e in d["kernels"].items():
+                if k.replace(" ", "").startswith(kernel.replace(">", ",").replace(" ", "")):
+                    c = e["counters"]
+        elif d.get("kernel") == kernel and d.get("workload", "").startswith(workload + " "):  # round 1/2 files
             c = d["counters"]
-            stream_reads = E2 * (8.0 * (Q - 1) + 4.0) + N * 4.0  # own old message record (Q-1 components) + index per edge, row offsets
-            return (c["FETCH_SIZE"]["per_launch_mean"] * 1024.0 + 0.5 * stream_reads + c["WRITE_SIZE"]["per_launch_mean"] * 1024.0,
-                    "from %s (same kernel sources)" % os.path.relpath(path, ROOT))
+        if c is None or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            continue
+        if d.get("source_sha") != sha:
+            stale = stale or "%s was collected on kernel sources %s, this build is %s" % (
+                os.path.relpath(path, ROOT), d.get("source_sha", "(unrecorded)"), sha)
+            continue
+        return (c["FETCH_SIZE"]["per_launch_mean"] * 1024.0 + 0.5 * stream_reads + c["WRITE_SIZE"]["per_launch_mean"] * 1024.0,
+                "from %s (same kernel sources)" % os.path.relpath(path, ROOT))
     return None, stale
 
 

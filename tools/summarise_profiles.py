@@ -30,32 +30,22 @@ except OSError:
     measured_sha = None
 if measured_sha and measured_sha != source_sha():
     print("NOTE: gpurun_out/profile_%s was measured on sources %s, the tree is now %s" % (R, measured_sha, source_sha()))
-counters = {}
-for d in sorted(glob.glob(os.path.join(OUT, "pmc_*"))) if measured_sha else []:
-    if not os.path.isdir(d):
-        continue
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        for row in csv.DictReader(open(f)):
-            if "k_sweep_psi" not in row.get("Kernel_Name", ""):
-                continue
-            counters.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-if counters:
-    try:
-        bench = json.loads(open(os.path.join(PROF, "%s_c3_bench.json" % R)).read())
-        kernel, e2 = bench["roofline"]["kernel"], bench["config"]["E2"]
-    except Exception:
-        kernel, e2 = "k_sweep_psi<4>", 100015584  # bench.py's default workload (seeded synthetic graph)
-    out = {"kernel": kernel, "workload": "C3 N=1e7 Q=4 c=10 (E2=%d)" % e2,
-           "source_sha": measured_sha,
-           "command": "rocprofv3 --kernel-trace --pmc <counter> --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline (one pass per counter; tools/profile_round.sh)",
-           "counters": {k: {"per_launch_mean": sum(v) / len(v), "launches": len(v)} for k, v in counters.items()}}
-    json.dump(out, open(os.path.join(PROF, "%s_c3_pmc_k_sweep_psi.json" % R), "w"), indent=1)
-    print(json.dumps(out["counters"]))
+import subprocess
+for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%s_*" % R))):
+    wl = os.path.basename(d).split("_")[-1]
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarise_pmc.py"), R, wl], check=False)
 if PMC_ONLY:
     sys.exit(0)
 for f in glob.glob(os.path.join(OUT, "budget_c3_w8_c*.json")):
     shutil.copy(f, os.path.join(PROF, "%s_%s" % (R, os.path.basename(f))))
-for name, dst in (("bench_rehearsal3.json", "%s_small_bench_3ranks_rehearsal.json"), ("bench_C3_rccl1.json", "%s_c3_bench_rccl_1rank.json")):
+for name, dst in (("infer_phases_C3.log", "%s_c3_infer_phases.log"), ("learn_C5.log", "%s_c5_learn_phases.log")):
+    if os.path.exists(os.path.join(OUT, name)):
+        shutil.copy(os.path.join(OUT, name), os.path.join(PROF, dst % R))
+st = glob.glob(os.path.join(OUT, "stats_infer_C3", "**", "*kernel_stats.csv"), recursive=True)
+if st:
+    shutil.copy(st[0], os.path.join(PROF, "%s_c3_infer_phases_kernel_stats.csv" % R))
+for name, dst in (("bench_rehearsal3.json", "%s_small_bench_3ranks_rehearsal.json"), ("bench_C3_rccl1.json", "%s_c3_bench_rccl_1rank.json"),
+                  ("bench_C3_200steps.json", "%s_c3_bench_200steps.json")):
     b = os.path.join(OUT, name)
     if os.path.exists(b):
         line = [l for l in open(b) if l.startswith("{")]
