@@ -48,6 +48,9 @@ WORKLOADS = {
     # power-law degrees cost
     "Q8": (1_000_000, 8, 8.0, 0.1, 0, 3),
     "Q8dc": (1_000_000, 8, 8.0, 0.1, 1, 3),
+    # label counts above 16: the matrix-core kernels (csrc/kernels_wide.h; message-gather form, full Q-component records)
+    "Q32": (1_000_000, 32, 8.0, 0.1, 0, 5),
+    "Q64": (500_000, 64, 8.0, 0.1, 0, 6),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 CONV_CRIT = 5e-6       # the reference's default -e (main.cpp:113)
@@ -505,7 +508,7 @@ def main():
                     "relaxation": list(runner.relaxation()[:2])}
 
     if rank == 0:
-        kname = ("k_sweep_psi<%d>" if st.psi_form_sweeps else "k_sweep<%d>") % Q
+        kname = ("k_wsweep<%d>" % ((Q + 15) // 16)) if Q > 16 else ("k_sweep_psi<%d>" if st.psi_form_sweeps else "k_sweep<%d>") % Q
         traffic, traffic_note = pmc_traffic(args.workload, kname, world, E2_total, N, Q)
         # the marginal-gather kernel's OWN minimum bytes (Q-1-component records, neighbour index instead of a reverse
         # index): stated next to SURVEY's work-unit figure, which `achieved` / `frac` use

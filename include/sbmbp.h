@@ -42,7 +42,8 @@ extern "C" {
 #define SBMBP_ERR_NOMEM (-7)
 #define SBMBP_ERR_COMM (-8)        /* a collective (RCCL or the caller's transport) failed */
 
-#define SBMBP_MAX_Q 16 /* label count handled by the templated kernels */
+#define SBMBP_MAX_Q 64 /* label counts 2 .. 16: lane-per-edge kernels (every mode, sharded too); 17 .. 64: matrix-core kernels
+                          (single engine, deg_corr_flag 0 / 1, cab > 0; kernels_wide.h) */
 
 typedef struct sbmbp_graph sbmbp_graph_t;   /* host-side CSR graph */
 typedef struct sbmbp_engine sbmbp_engine_t; /* device engine (one GPU) */
@@ -229,7 +230,7 @@ typedef struct sbmbp_shard_desc {
     const uint64_t *row_ptr;    /* host [n_own+1], local offsets */
     const uint32_t *nbr_local;  /* host [n_edges]: index into the marginal table: own < n_own <= halo */
     void *psi_buf0, *psi_buf1;  /* device, (n_own+n_halo)*Q doubles each */
-    void *red_buf;              /* device, >= SBMBP_RED_GATHER_OFFSET + n_ranks * SBMBP_FOLD_ROWS * (SBMBP_MAX_Q + 1) doubles (and >= 8192):
+    void *red_buf;              /* device, >= SBMBP_RED_GATHER_OFFSET + n_ranks * SBMBP_FOLD_ROWS * 17 doubles (and >= 8192):
                                    reduction hand-off buffer */
     uint32_t n_chunks;          /* row chunks for overlapping the halo exchange with the sweep (0 or 1 = none) */
     const uint32_t *chunk_row;  /* host [n_chunks+1] local row boundaries, chunk_row[0] = 0, last = n_own */
@@ -303,7 +304,7 @@ int sbmbp_shard_sweep_chunk(sbmbp_engine_t *e, uint32_t j, uint32_t c);
 int sbmbp_shard_sweep_chunk_on(sbmbp_engine_t *e, uint32_t j, uint32_t c, void *hip_stream);
 int sbmbp_shard_sweep_fold(sbmbp_engine_t *e);
 #define SBMBP_FOLD_ROWS 64          /* rows of (Q+1) doubles sbmbp_shard_sweep_fold leaves at red[0..) */
-#define SBMBP_RED_GATHER_OFFSET 2048 /* > SBMBP_FOLD_ROWS * (SBMBP_MAX_Q + 1): gathered rows never overlap a shard's own rows */
+#define SBMBP_RED_GATHER_OFFSET 2048 /* > SBMBP_FOLD_ROWS * 17 (sharded engines: Q <= 16): gathered rows never overlap a shard's own rows */
 /* consume the reduction values: n_rows rows of (Q+1) doubles starting at red + SBMBP_RED_GATHER_OFFSET (the caller
  * all-gathers every shard's red[0..Q] there; n_rows = number of shards). Rows are folded in order —
  * sums for the Q field entries, max for the hint. mode 0 after a sweep, 1 field initialisation */

@@ -275,11 +275,12 @@ class BeliefPropagation:
         check(self._lib.sbmbp_confusion(self._h, _dp(Cm)))
         return Cm
 
-    def em_expectations(self):
-        """compute_na_expect + compute_cab_expect (belief_propagation.cpp:428-440, 892-989)"""
-        na, nna, cab = np.zeros(self.Q), np.zeros(self.Q), np.zeros((self.Q, self.Q))
-        check(self._lib.sbmbp_em_expectations(self._h, _dp(na), _dp(nna), _dp(cab)))
-        return na, nna, cab
+    def em_expectations(self, cab=True):
+        """compute_na_expect + compute_cab_expect (belief_propagation.cpp:428-440, 892-989); cab=False: the group sizes only
+        (above Q = 16 the cab expectations, i.e. -m learn, are not implemented)"""
+        na, nna, cabe = np.zeros(self.Q), np.zeros(self.Q), np.zeros((self.Q, self.Q))
+        check(self._lib.sbmbp_em_expectations(self._h, _dp(na), _dp(nna), _dp(cabe) if cab else None))
+        return na, nna, cabe
 
     def inference(self, blockmodel, state, conv_crit, time_conv, dumping_rate):
         """belief_propagation.cpp:77-99; returns the result struct (format_infer_line prints it)"""

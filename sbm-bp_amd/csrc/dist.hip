@@ -993,7 +993,7 @@ extern "C" {
 int sbmbp_dist_create(sbmbp_dist_t **out, sbmbp_comm_t *comm, const sbmbp_graph_t *g, uint32_t Q, uint32_t dc, int device,
                       uint32_t n_chunks) {
     if (!out || !comm || !g) return SBMBP_ERR_ARG;
-    if (Q < 2 || Q > SBMBP_MAX_Q) { set_error("Q must be in [2, 16]"); return SBMBP_ERR_UNSUPPORTED; }
+    if (Q < 2 || Q > 16) { set_error("the multi-GPU driver handles Q in [2, 16]"); return SBMBP_ERR_UNSUPPORTED; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device visible; the engine has no CPU fallback"); return SBMBP_ERR_NODEVICE; }
     if (device >= 0) HIPCHK(hipSetDevice(device));
@@ -1019,7 +1019,7 @@ int sbmbp_dist_create(sbmbp_dist_t **out, sbmbp_comm_t *comm, const sbmbp_graph_
         CHK(dalloc(&d->d_recvbuf[t], size_t(P.n_halo) * d->ncomp));
         HIPCHK(hipMemset(d->d_recvbuf[t], 0, std::max<size_t>(1, size_t(P.n_halo) * d->ncomp) * 8));
     }
-    const size_t red_cap = std::max<size_t>(8192, SBMBP_RED_GATHER_OFFSET + size_t(d->world) * SBMBP_FOLD_ROWS * (SBMBP_MAX_Q + 1));
+    const size_t red_cap = std::max<size_t>(8192, SBMBP_RED_GATHER_OFFSET + size_t(d->world) * SBMBP_FOLD_ROWS * (16 + 1));
     CHK(dalloc(&d->d_red, red_cap));
     HIPCHK(hipMemset(d->d_red, 0, red_cap * 8));
     CHK(dalloc(&d->d_sendbuf, P.send_idx_chunked.size() * d->ncomp));

@@ -17,6 +17,7 @@
 #include "../../include/sbmbp.h"
 #include "host_graph.h"
 #include "kernels.h"
+#include "kernels_wide.h"
 
 using namespace sbmbp;
 
@@ -40,6 +41,8 @@ struct sbmbp_engine {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     uint32_t N = 0, Q = 0, dc = 0;  // N = rows this engine updates (all vertices, or the owned range of a shard)
+    bool wide = false;              // Q > 16: the matrix-core kernels of kernels_wide.h (full Q-component message records)
+    dev_wide *d_Pw = nullptr;
     uint64_t E2 = 0;
     // sharding (sbmbp_shard_create): marginal table = owned rows followed by halo vertices
     bool sharded = false, ext_psi = false;
@@ -174,8 +177,21 @@ const double *fold_stage(sbmbp_engine *e, uint32_t *rows, int ncols_sum, int has
     return e->d_stage;
 }
 
-inline int frame_cap(uint32_t Q) { return (Q <= 4 ? FTPB : SBMBP_FRAME_TPB_HI) * (Q <= 2 ? SBMBP_EPT_LO : (Q <= 4 ? SBMBP_EPT_MID : (Q <= 8 ? SBMBP_EPT_HI : 1))); }
-inline int frame_rcap(uint32_t Q) { const int cap = frame_cap(Q); return cap / 2 > 64 ? cap / 2 : 64; }
+inline int frame_cap(uint32_t Q) {
+    if (Q > 16) return WCAP;
+    return (Q <= 4 ? FTPB : SBMBP_FRAME_TPB_HI) * (Q <= 2 ? SBMBP_EPT_LO : (Q <= 4 ? SBMBP_EPT_MID : (Q <= 8 ? SBMBP_EPT_HI : 1)));
+}
+inline int frame_rcap(uint32_t Q) { if (Q > 16) return WRCAP; const int cap = frame_cap(Q); return cap / 2 > 64 ? cap / 2 : 64; }
+inline size_t rec_len(const sbmbp_engine *e) { return e->wide ? e->Q : e->Q - 1; }  // doubles per message record in HBM
+
+// label counts above 16: QT = tiles of 16 labels (kernels_wide.h)
+#define DISPATCH_QT(Qv, ...)                                            \
+    switch (((Qv) + 15) / 16) {                                         \
+        case 2: { constexpr int QT = 2; __VA_ARGS__; } break;           \
+        case 3: { constexpr int QT = 3; __VA_ARGS__; } break;           \
+        case 4: { constexpr int QT = 4; __VA_ARGS__; } break;           \
+        default: set_error("unsupported Q"); return SBMBP_ERR_UNSUPPORTED; \
+    }
 
 // Q/dc dispatch over the templated kernels. -DSBMBP_ONLY_Q=<q> instantiates ONE label count: tuning builds that compile in a
 // fraction of the time (sbm_bp_amd.build.build_variant; never the shipped library).
@@ -211,15 +227,32 @@ int upload_params(sbmbp_engine *e, double crit, bool hinted = false) {
     dev_params P;
     std::memset(&P, 0, sizeof P);
     const uint32_t Q = e->Q;
+    if (e->wide) {  // the Q x Q matrices and Q-vectors live in dev_wide; dev_params keeps the scalars and the convergence state
+        std::unique_ptr<dev_wide> Wd(new dev_wide());
+        std::memset(Wd.get(), 0, sizeof(dev_wide));
+        std::vector<double> cl(Q * Q);
+        for (uint32_t a = 0; a < Q * Q; ++a) {
+            Wd->cab[a] = e->cab[a];
+            Wd->W[a] = (e->dc == 0) ? std::pow(e->cab[a], e->beta) : e->cab[a];
+            Wd->logcab[a] = std::log(e->cab[a]);
+            cl[a] = e->cab[a] * Wd->logcab[a];
+        }
+        for (uint32_t q = 0; q < Q; ++q) { Wd->eta[q] = e->eta[q]; Wd->logeta[q] = std::log(e->eta[q]); }
+        wide_tiles(Wd->W, int(Q), Wd->tW);
+        wide_tiles(Wd->cab, int(Q), Wd->tC);
+        wide_tiles(cl.data(), int(Q), Wd->tCL);
+        HIPCHK(hipMemcpyAsync(e->d_Pw, Wd.get(), sizeof(dev_wide), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    } else
     for (uint32_t a = 0; a < Q * Q; ++a) {
         P.cab[a] = e->cab[a];
         P.W[a] = (e->dc == 0) ? std::pow(e->cab[a], e->beta) : (e->dc == 1 ? e->cab[a] : e->cab[a] / double(e->Nglob));
     }
-    for (uint32_t q = 0; q < Q; ++q) {
+    for (uint32_t q = 0; q < Q && !e->wide; ++q) {
         P.eta[q] = e->eta[q];
         P.logeta[q] = std::log(e->eta[q]);
     }
-    for (uint32_t a = 0; a < Q * Q; ++a) P.logcab[a] = std::log(e->cab[a]);
+    for (uint32_t a = 0; a < Q * Q && !e->wide; ++a) P.logcab[a] = std::log(e->cab[a]);
     P.beta = e->beta;
     P.invN = 1.0 / double(e->Nglob);
     P.field_mix = e->field_mix;
@@ -302,10 +335,23 @@ int launch_hub_msg(sbmbp_engine *e, hipStream_t st, const double *Mold, double *
 }
 
 // h from the current psi (init_h, bp.cpp:320-332); mode 1 = converge start, 2 = exact refresh
+// wide path: fold of [rows][Q + 1] records (long tables to <= FOLD_BLOCKS rows first) + k_wfinalize
+int launch_wfinalize(sbmbp_engine *e, uint32_t rows, int mode) {
+    const double *part = fold_stage(e, &rows, int(e->Q), 1, e->Q + 1);
+    hipLaunchKernelGGL(k_wfinalize, dim3(1), dim3(BLOCK), 0, e->stream, part, rows, mode, e->d_P, e->d_Pw, int(e->Q), e->d_hist, e->hist_cap);
+    HIPCHK(hipGetLastError());
+    return SBMBP_OK;
+}
+
 int launch_field(sbmbp_engine *e, int mode) {
     const uint32_t rows_per_blk = 4096;
     const uint32_t nb = std::max<uint32_t>(1, (e->N + rows_per_blk - 1) / rows_per_blk);
     CHK(ensure_partials(e, size_t(nb) * (e->Q + 1)));
+    if (e->wide) {
+        hipLaunchKernelGGL(k_wpsi_sum, dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_psi[e->pcur], e->N, rows_per_blk, int(e->Q),
+                           int(e->dc != 0), e->d_partials);
+        return launch_wfinalize(e, nb, mode);
+    }
     DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_psi_sum<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_psi[e->pcur],
                                         e->N, rows_per_blk, int(e->dc != 0), e->d_partials));
     DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_finalize<QQ>), dim3(1), dim3(BLOCK), 0, e->stream, e->d_partials, nb, mode, e->d_P,
@@ -324,6 +370,23 @@ int launch_sweep(sbmbp_engine *e, uint32_t j, double damp, bool psi_form, bool f
     const double *psi_old = e->d_psi[pc];
     double *psi_new = e->d_psi[pc ^ 1];
     const int32_t *clamp = e->has_clamp ? e->d_clamp : nullptr;
+    if (e->wide) {  // Q > 16: one kernel for rows of any degree, then the fold and K2 for a run-time Q
+        hipEvent_t w0 = nullptr, w1 = nullptr;
+        if (e->timing) {
+            if (e->ev_used + 2 > e->ev.size()) {
+                size_t old = e->ev.size();
+                e->ev.resize(old + 256);
+                for (size_t i = old; i < e->ev.size(); ++i) HIPCHK(hipEventCreate(&e->ev[i]));
+            }
+            w0 = e->ev[e->ev_used++];
+            w1 = e->ev[e->ev_used++];
+            HIPCHK(hipEventRecord(w0, e->stream));
+        }
+        DISPATCH_QT(e->Q, hipLaunchKernelGGL((k_wsweep<QT>), dim3(e->n_blk), dim3(WTPB), 0, e->stream, e->d_row_ptr, e->d_rev, Mold, Mnew, psi_old,
+                                             psi_new, clamp, e->d_blk_row, e->d_blk_e0, e->d_P, e->d_Pw, int(e->Q), int(e->dc), damp, e->d_partials));
+        if (e->timing) HIPCHK(hipEventRecord(w1, e->stream));
+        return launch_wfinalize(e, e->n_blk, 0);
+    }
     // Hub rows first, in fragments, on the sweep's own stream (disjoint rows and edges from the frame kernel's; they are
     // throughput-bound like it: beside it on a second stream they gained nothing, C4 0.545 vs 0.533 ms per sweep; round 3
     // let the fragment PRODUCTS ride at the head of the frame launch instead of a launch of their own, and the frame kernel
@@ -410,6 +473,8 @@ int message_diff(sbmbp_engine *e, double *out) {
     if (n == 0) { *out = 0.0; return SBMBP_OK; }
     const uint32_t nb = uint32_t(std::min<uint64_t>(2048, (n + BLOCK - 1) / BLOCK));
     CHK(ensure_partials(e, size_t(nb) * 2));
+    if (e->wide) hipLaunchKernelGGL(k_wmsg_diff, dim3(nb), dim3(BLOCK), 0, e->stream, e->d_M[0], e->d_M[1], n * e->Q, e->d_partials);
+    else
     DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_msg_diff<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_M[0], e->d_M[1], n, e->d_partials));
     hipLaunchKernelGGL(k_fold_stage, dim3(1), dim3(BLOCK), 0, e->stream, e->d_partials, nb, nb, 1, 1, 2u, e->d_stage);
     HIPCHK(hipGetLastError());
@@ -421,7 +486,7 @@ int message_diff(sbmbp_engine *e, double *out) {
 }
 
 bool psi_form_allowed(const sbmbp_engine *e, double damping) {
-    return e->gather_mode == 0 && damping == 1.0 && (!e->has_clamp || e->clamp_onehot) && e->dc != 2 && e->w_positive && e->E2 > 0;
+    return !e->wide && e->gather_mode == 0 && damping == 1.0 && (!e->has_clamp || e->clamp_onehot) && e->dc != 2 && e->w_positive && e->E2 > 0;
 }
 
 // run sweeps until convergence (crit >= 0) or exactly max_sweeps (crit < 0: never converges). The whole decision runs on
@@ -591,6 +656,8 @@ bool fused_ok(const sbmbp_engine *e) {
     return e->fused_reductions && !e->sharded && e->psi_consistent && psi_form_allowed(e, 1.0);
 }
 
+inline bool use_fz(const sbmbp_engine *e) { return e->wide || fused_ok(e); }  // (the wide path has no other reduction kernels)
+
 // ONE pass: site / edge terms of free energy (and entropy), adjacent pairs of the non-edge term (dc 0), EM numerators.
 // Results stay in e->fz until the state changes.
 int fused_pass(sbmbp_engine *e, bool want_entropy, bool want_em) {
@@ -605,6 +672,24 @@ int fused_pass(sbmbp_engine *e, bool want_entropy, bool want_em) {
         CHK(upload_nonedge_mats(e, mats, nullptr));
         adj_mode = nonedge_exact(e) ? 2 : 1;
         d_w = adj_mode == 2 ? e->d_mats + Q * Q : e->d_mats;
+    }
+    if (e->wide) {  // Q > 16: k_wreduce (message-gather, matrix cores), hub rows included
+        CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (WR_NP + 1)));
+        CHK(ensure_small(e, WR_NP));
+        DISPATCH_QT(Q, hipLaunchKernelGGL((k_wreduce<QT>), dim3(e->n_blk), dim3(WTPB), 0, e->stream, e->d_row_ptr, e->d_rev, e->d_nbr,
+                                          e->d_M[e->cur], e->d_psi[e->pcur], e->d_blk_row, e->d_blk_e0, e->d_P, e->d_Pw, int(Q), int(e->dc),
+                                          int(want_entropy), adj_mode, d_w, e->d_partials));
+        HIPCHK(hipGetLastError());
+        double o6[WR_NP];
+        CHK(fold_to_host(e, e->n_blk, WR_NP, WR_NP + 1, o6));
+        for (int x = 0; x < 4; ++x) e->fz.se[x] = o6[x];
+        e->fz.adj[0] = o6[FE_NP];
+        e->fz.adj[1] = o6[FE_NP + 1];
+        e->fz.tri.clear();
+        e->fz.valid = true;
+        e->fz.entropy = want_entropy;
+        e->fz.em = false;
+        return SBMBP_OK;
     }
     const uint32_t T = want_em ? Q * (Q + 1) / 2 : 0, NP = FE_NP + NE_NP + T, rows = e->n_blk + e->n_hub;
     CHK(ensure_partials(e, size_t(std::max<uint32_t>(rows, 1)) * (NP + 1)));
@@ -637,7 +722,7 @@ int fused_pass(sbmbp_engine *e, bool want_entropy, bool want_em) {
 }
 
 int site_edge_terms(sbmbp_engine *e, bool want_entropy, double out[4], double *d_out = nullptr) {
-    if (d_out == nullptr && fused_ok(e)) {
+    if (d_out == nullptr && use_fz(e)) {
         CHK(fused_pass(e, want_entropy, false));
         for (int x = 0; x < 4; ++x) out[x] = e->fz.se[x];
         return SBMBP_OK;
@@ -723,15 +808,25 @@ int nonedge_terms(sbmbp_engine *e, bool want_entropy, double out[2]) {
     const double *d_w = e->d_mats, *d_Pm = e->d_mats + Q * Q, *d_cab = e->d_mats + 2 * Q * Q;
     const bool exact = nonedge_exact(e);
     double adj[2] = {0.0, 0.0}, all[2] = {0.0, 0.0};
-    const bool adj_known = fused_ok(e) && e->fz.valid && (e->fz.entropy || !want_entropy);  // the fused pass has the adjacent pairs already
+    const bool adj_known = use_fz(e) && e->fz.valid && (e->fz.entropy || !want_entropy);  // the fused pass has the adjacent pairs already
+    if (e->wide && !adj_known) { set_error("internal: the wide reductions run site_edge_terms first"); return SBMBP_ERR_STATE; }
     if (adj_known) { adj[0] = e->fz.adj[0]; adj[1] = e->fz.adj[1]; }
     if (exact) {
         const uint32_t g = (N + BLOCK - 1) / BLOCK;
         CHK(ensure_partials(e, size_t(g) * g * (NE_NP + 1)));
+        if (e->wide) {
+            const uint32_t gw = (N + 63) / 64;
+            CHK(ensure_partials(e, size_t(gw) * gw * (NE_NP + 1)));
+            hipLaunchKernelGGL(k_wnonedge_exact, dim3(gw, gw), dim3(BLOCK), 0, e->stream, e->d_psi[e->pcur], N, int(Q), d_Pm, d_cab, invN,
+                               int(want_entropy), e->d_partials);
+            HIPCHK(hipGetLastError());
+            CHK(fold_to_host(e, gw * gw, NE_NP, NE_NP + 1, all));
+        } else {
         DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_exact<QQ>), dim3(g, g), dim3(BLOCK), 0, e->stream, e->d_psi[e->pcur], N,
                                          e->d_psi[e->pcur], N, d_Pm, d_cab, invN, int(want_entropy), e->d_partials));
         HIPCHK(hipGetLastError());
         CHK(fold_to_host(e, g * g, NE_NP, NE_NP + 1, all));
+        }
         if (!adj_known) {
         CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (NE_NP + 1)));
         DISPATCH_Q(Q, hipLaunchKernelGGL((k_nonedge_exact_adj<QQ>), dim3(e->n_blk), dim3(frame_cfg<QQ>::TPB), 0, e->stream, e->d_row_ptr,
@@ -792,6 +887,10 @@ int row_sums(sbmbp_engine *e, std::vector<double> &out /* 2Q + Q*Q */) {
     const uint32_t nb = std::max<uint32_t>(1, (e->N + rows_per_blk - 1) / rows_per_blk);
     CHK(ensure_partials(e, size_t(nb) * T));
     CHK(ensure_small(e, T));
+    if (e->wide)
+        hipLaunchKernelGGL(k_wrow_sums, dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_psi[e->pcur], e->d_true, e->N, rows_per_blk,
+                           int(Q), e->d_partials);
+    else
     DISPATCH_Q(Q, hipLaunchKernelGGL((k_row_sums<QQ>), dim3(nb), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_psi[e->pcur],
                                      e->d_true, e->N, rows_per_blk, e->d_partials));
     HIPCHK(hipGetLastError());
@@ -808,6 +907,12 @@ int em_expect(sbmbp_engine *e, double *na_e, double *nna_e, double *cab_e) {
     std::vector<double> rs;
     CHK(row_sums(e, rs));
     const double *na = rs.data(), *nna = rs.data() + Q;
+    if (e->wide) {
+        if (cab_e) { set_error("the EM expectations of cab (-m learn) are implemented up to Q = 16"); return SBMBP_ERR_UNSUPPORTED; }
+        if (na_e) std::copy(na, na + Q, na_e);
+        if (nna_e) std::copy(nna, nna + Q, nna_e);
+        return SBMBP_OK;
+    }
     const uint32_t T = Q * (Q + 1) / 2;
     std::vector<double> tri(T);
     if (fused_ok(e) && Q <= 8) {
@@ -1005,8 +1110,9 @@ int sbmbp_param_from_direct(uint32_t N, uint32_t Q, const double *pa, const doub
 
 int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint32_t dc, int device) {
     if (!out || !g) return SBMBP_ERR_ARG;
-    if (Q < 2 || Q > SBMBP_MAX_Q) { set_error("Q must be in [2, 16]"); return SBMBP_ERR_UNSUPPORTED; }
+    if (Q < 2 || Q > SBMBP_MAX_Q) { set_error("Q must be in [2, 64]"); return SBMBP_ERR_UNSUPPORTED; }
     if (dc > 2) { set_error("deg_corr_flag must be 0, 1 or 2"); return SBMBP_ERR_ARG; }
+    if (Q > 16 && dc == 2) { set_error("deg_corr_flag 2 is implemented up to Q = 16"); return SBMBP_ERR_UNSUPPORTED; }
     if (g->n == 0) { set_error("empty graph"); return SBMBP_ERR_ARG; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -1020,6 +1126,7 @@ int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint3
     e->Nglob = g->n;
     e->Q = Q;
     e->dc = dc;
+    e->wide = Q > 16;
     e->E2 = g->e2();
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->own_stream = true;
@@ -1061,8 +1168,9 @@ int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint3
     TRY(dev_alloc(e, &e->d_hub_blk, hub_blk.size()));
     TRY(dev_alloc(e, &e->d_true, e->N));
     TRY(dev_alloc(e, &e->d_clamp, e->N));
-    TRY(dev_alloc(e, &e->d_M[0], std::max<uint64_t>(e->E2, 1) * (Q - 1)));  // records of Q-1 components; >= one record: the sweep's loads are branch-free
-    TRY(dev_alloc(e, &e->d_M[1], std::max<uint64_t>(e->E2, 1) * (Q - 1)));
+    TRY(dev_alloc(e, &e->d_M[0], std::max<uint64_t>(e->E2, 1) * rec_len(e)));  // records of Q-1 components (Q above 16 labels); >= one record: the sweep's loads are branch-free
+    TRY(dev_alloc(e, &e->d_M[1], std::max<uint64_t>(e->E2, 1) * rec_len(e)));
+    if (e->wide) TRY(dev_alloc(e, &e->d_Pw, 1));
     TRY(dev_alloc(e, &e->d_psi[0], size_t(e->N) * Q));
     TRY(dev_alloc(e, &e->d_psi[1], size_t(e->N) * Q));
     TRY(dev_alloc(e, &e->d_P, 1));
@@ -1090,7 +1198,7 @@ int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint3
     if (e->n_hub) {
         TRYHIP(hipMemcpyAsync(e->d_hub_row, hub_row.data(), hub_row.size() * 4, hipMemcpyHostToDevice, e->stream));
         TRYHIP(hipMemcpyAsync(e->d_hub_blk, hub_blk.data(), hub_blk.size() * 4, hipMemcpyHostToDevice, e->stream));
-        TRY(setup_hub_frags(e, hub_row, rp32));
+        if (!e->wide) TRY(setup_hub_frags(e, hub_row, rp32));  // (the wide sweep walks a long row itself)
     }
     TRYHIP(hipMemsetAsync(e->d_true, 0, size_t(e->N) * 4, e->stream));
     TRYHIP(hipMemsetAsync(e->d_clamp, 0xff, size_t(e->N) * 4, e->stream));
@@ -1123,7 +1231,7 @@ void sbmbp_destroy(sbmbp_engine_t *e) {
     if (e->ext_psi) e->d_psi[0] = e->d_psi[1] = nullptr;  // caller-owned
     void *ptrs[] = {e->d_deg, e->d_row_ptr, e->d_rev, e->d_nbr, e->d_src, e->d_blk_row, e->d_blk_e0, e->d_hub_row, e->d_hub_blk, e->d_true,
                     e->d_clamp, e->d_M[0], e->d_M[1], e->d_psi[0], e->d_psi[1], e->d_Min, e->d_snd_ptr, e->d_snd_slot, e->d_P, e->d_partials, e->d_small, e->d_hist, e->d_mats,
-                    e->d_stage, e->d_frag_hub, e->d_hub_frag0, e->d_hub_b, e->d_hub_pA, e->d_hub_pE, e->d_fold_counters};
+                    e->d_stage, e->d_frag_hub, e->d_hub_frag0, e->d_hub_b, e->d_hub_pA, e->d_hub_pE, e->d_fold_counters, e->d_Pw};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto ev : e->ev) hipEventDestroy(ev);
     if (e->h_cs) (void)hipHostFree(e->h_cs);
@@ -1194,16 +1302,20 @@ int sbmbp_init_messages(sbmbp_engine_t *e, uint32_t flag, const int32_t *conf, c
         herr = hipMemcpyAsync(e->d_psi[e->pcur] + size_t(lo) * Q, prow, size_t(hi - lo) * Q * 8, hipMemcpyHostToDevice, e->stream);
         const uint64_t k0 = e->h_row_ptr[lo], nm = uint64_t(e->h_row_ptr[hi]) - k0;
         if (herr == hipSuccess && nm) {
-            if (nm > tmp_cap) {
+            if (nm > tmp_cap && !e->wide) {
                 if (tmp) { (void)hipStreamSynchronize(e->stream); (void)hipFree(tmp); tmp = nullptr; }
                 herr = hipMalloc(&tmp, nm * Q * 8);
                 tmp_cap = herr == hipSuccess ? nm : 0;
             }
+            if (e->wide) {  // full records: straight into the message buffer
+                herr = hipMemcpyAsync(e->d_M[e->cur] + k0 * Q, mrow, nm * Q * 8, hipMemcpyHostToDevice, e->stream);
+            } else {
             if (herr == hipSuccess) herr = hipMemcpyAsync(tmp, mrow, nm * Q * 8, hipMemcpyHostToDevice, e->stream);
             if (herr == hipSuccess) {
                 hipLaunchKernelGGL(k_msgs_to_records, dim3(uint32_t((nm + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, e->stream, tmp, nm,
                                    int(Q), e->d_M[e->cur] + k0 * (Q - 1));
                 herr = hipGetLastError();
+            }
             }
         }
         if (herr == hipSuccess) herr = hipStreamSynchronize(e->stream);  // the slab buffers are reused by the next slab
@@ -1243,7 +1355,10 @@ int sbmbp_init_messages_device(sbmbp_engine_t *e, uint64_t seed, const uint32_t 
     // every out-message of a row starts as the row's marginal
     hipLaunchKernelGGL(k_init_random, dim3((e->N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_psi[e->pcur], uint64_t(e->N),
                        int(e->Q), int(e->Q), seed, 0x1234567ull, uint64_t(e->row0));
-    if (e->E2)
+    if (e->E2 && e->wide)
+        hipLaunchKernelGGL(k_winit_msgs_from_psi, dim3(e->N), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_psi[e->pcur], e->N, int(e->Q),
+                           e->d_M[0], e->d_M[1]);
+    else if (e->E2)
         hipLaunchKernelGGL(k_init_msgs_from_psi, dim3((e->N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
                            e->d_psi[e->pcur], e->N, int(e->Q), e->d_M[0], e->d_M[1]);
     HIPCHK(hipGetLastError());
@@ -1260,6 +1375,7 @@ int sbmbp_set_params(sbmbp_engine_t *e, const double *cab, const uint32_t *na, d
     device_scope dev_(e);
     if (!e || !cab || !na) return SBMBP_ERR_ARG;
     apply_params_host(e, cab, na, beta);
+    if (e->wide && !e->w_positive) { set_error("above Q = 16 every cab entry must be > 0"); e->have_params = false; return SBMBP_ERR_UNSUPPORTED; }
     return upload_params(e, 0.0);
 }
 int sbmbp_get_params(sbmbp_engine_t *e, double *cab, uint32_t *na) {
@@ -1275,6 +1391,11 @@ int sbmbp_get_params(sbmbp_engine_t *e, double *cab, uint32_t *na) {
 static constexpr uint64_t STATE_SLAB = uint64_t(16) << 20;  // messages per staging pass
 
 static int upload_messages(sbmbp_engine *e, const double *msg_out, double *dst) {
+    if (e->wide) {  // full records on the device too
+        HIPCHK(hipMemcpyAsync(dst, msg_out, e->E2 * e->Q * 8, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        return SBMBP_OK;
+    }
     const uint64_t slab = std::min<uint64_t>(e->E2, STATE_SLAB);
     double *tmp = nullptr;
     HIPCHK(hipMalloc(&tmp, slab * e->Q * 8));
@@ -1295,6 +1416,11 @@ static int upload_messages(sbmbp_engine *e, const double *msg_out, double *dst) 
 }
 
 static int download_messages(sbmbp_engine *e, const double *src, double *msg_out) {
+    if (e->wide) {
+        HIPCHK(hipMemcpyAsync(msg_out, src, e->E2 * e->Q * 8, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        return SBMBP_OK;
+    }
     const uint64_t slab = std::min<uint64_t>(e->E2, STATE_SLAB);
     double *tmp = nullptr;
     HIPCHK(hipMalloc(&tmp, slab * e->Q * 8));
@@ -1340,6 +1466,13 @@ int sbmbp_get_field(sbmbp_engine_t *e, double *h) {
     if (!e || !h) return SBMBP_ERR_ARG;
     NOT_SHARD(e);
     CHK(refresh_field(e));
+    if (e->wide) {
+        std::vector<double> hn(e->Q);
+        HIPCHK(hipMemcpyAsync(hn.data(), reinterpret_cast<const char *>(e->d_Pw) + offsetof(dev_wide, hN), size_t(e->Q) * 8, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        for (uint32_t q = 0; q < e->Q; ++q) h[q] = hn[q] * double(e->N);
+        return SBMBP_OK;
+    }
     dev_params P;
     HIPCHK(hipMemcpyAsync(&P, e->d_P, sizeof P, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -1555,7 +1688,7 @@ int sbmbp_set_timing(sbmbp_engine_t *e, int on) {
 
 int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *d, uint32_t Q, uint32_t dc, int device) {
     if (!out || !d || !d->row_ptr || (!d->nbr_local && d->n_edges) || !d->psi_buf0 || !d->psi_buf1 || !d->red_buf) return SBMBP_ERR_ARG;
-    if (Q < 2 || Q > SBMBP_MAX_Q) { set_error("Q must be in [2, 16]"); return SBMBP_ERR_UNSUPPORTED; }
+    if (Q < 2 || Q > 16) { set_error("sharded engines: Q must be in [2, 16]"); return SBMBP_ERR_UNSUPPORTED; }
     if (dc > 2) { set_error("deg_corr_flag must be 0, 1 or 2"); return SBMBP_ERR_ARG; }
     if (dc == 2 && (!d->rev_local || !d->table_deg)) { set_error("a dc 2 shard needs rev_local and table_deg (it runs the message-gather sweep)"); return SBMBP_ERR_ARG; }
     if (d->n_halo_msgs && !d->rev_local) { set_error("n_halo_msgs without rev_local"); return SBMBP_ERR_ARG; }

@@ -19,7 +19,8 @@
 namespace sbmbp {
 
 constexpr int BLOCK = 256;
-constexpr int QMAX = 16;
+constexpr int QMAX = 16;     // label counts of the lane-per-edge kernels and of dev_params
+constexpr int QMAX_RT = 64;  // ... of the run-time-Q helper kernels (initial state, record conversion): also above 16
 
 // Parameter/state block in HBM, read through scalar loads by every workgroup and rewritten by
 // k_finalize after each sweep (arrays packed with stride Q).
@@ -2235,8 +2236,9 @@ k_moments(const double *__restrict__ psi, uint32_t n_rows, int Q, int K, uint32_
     const int sub = nsub > 1 ? tid / T : 0;
     const bool active = nsub == 1 || tid < nsub * T;
     const uint32_t lo = blockIdx.x * rows_per_blk, hi = min(n_rows, lo + rows_per_blk);
-    for (uint32_t base = lo; base < hi; base += BLOCK) {
-        const uint32_t cnt = min(uint32_t(BLOCK), hi - base);
+    const uint32_t stage_rows = Q <= QMAX ? uint32_t(BLOCK) : uint32_t(BLOCK * QMAX / Q);  // (label counts above 16: fewer rows per stage)
+    for (uint32_t base = lo; base < hi; base += stage_rows) {
+        const uint32_t cnt = min(stage_rows, hi - base);
         __syncthreads();
         for (uint32_t x = tid; x < cnt * Q; x += BLOCK) sp[x] = psi[size_t(base) * Q + x];
         __syncthreads();
@@ -2559,7 +2561,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_init_random(double *__restrict__ v, uint64_t n_vec, int Q, int ncomp, uint64_t seed, uint64_t salt, uint64_t index0) {
     const uint64_t i = uint64_t(blockIdx.x) * BLOCK + threadIdx.x;
     if (i >= n_vec) return;
-    double t[QMAX], w[QMAX], norm = 0.0;
+    double t[QMAX_RT], w[QMAX_RT], norm = 0.0;
     for (int q = 0; q < Q; ++q) { t[q] = u01(seed ^ salt, (index0 + i) * uint64_t(Q) + q); norm += t[q]; }
     for (int q = 0; q < Q; ++q) t[q] /= norm;
     if (ncomp == Q) {
@@ -2578,7 +2580,7 @@ k_init_msgs_from_psi(const uint32_t *__restrict__ row_ptr, const double *__restr
                      double *__restrict__ Ma, double *__restrict__ Mb) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n_rows) return;
-    double v[QMAX], w[QMAX];
+    double v[QMAX_RT], w[QMAX_RT];
     for (int q = 0; q < Q; ++q) v[q] = psi[size_t(i) * Q + q];
     encode_msg_rt(v, Q, w);
     for (uint32_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k)
@@ -2590,7 +2592,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_msgs_to_records(const double *__restrict__ full, uint64_t n_msg, int Q, double *__restrict__ rec) {
     const uint64_t k = uint64_t(blockIdx.x) * BLOCK + threadIdx.x;
     if (k >= n_msg) return;
-    double v[QMAX], w[QMAX];
+    double v[QMAX_RT], w[QMAX_RT];
     for (int q = 0; q < Q; ++q) v[q] = full[k * Q + q];
     encode_msg_rt(v, Q, w);
     for (int q = 0; q < Q - 1; ++q) rec[k * (Q - 1) + q] = w[q];
@@ -2599,7 +2601,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_records_to_msgs(const double *__restrict__ rec, uint64_t n_msg, int Q, double *__restrict__ full) {
     const uint64_t k = uint64_t(blockIdx.x) * BLOCK + threadIdx.x;
     if (k >= n_msg) return;
-    double v[QMAX], w[QMAX];
+    double v[QMAX_RT], w[QMAX_RT];
     for (int q = 0; q < Q - 1; ++q) w[q] = rec[k * (Q - 1) + q];
     decode_msg_rt(w, Q, v);
     for (int q = 0; q < Q; ++q) full[k * Q + q] = v[q];

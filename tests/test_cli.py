@@ -144,6 +144,38 @@ def test_reference_flags_only_converge_on_the_oscillating_hub_instance(gpus):
     assert abs(float(f) - g["f"]) < 1e-9 and abs(float(e) - g["e"]) < 1e-8 and abs(float(ov) - g["overlap"]) < 1e-9
 
 
+@pytest.mark.gpu
+def test_more_than_sixteen_blocks(tmp_path, orc):
+    """the reference has no cap on the number of blocks (main.cpp:271); bin/bp takes up to 64 (matrix-core kernels above 16):
+    -m infer at Q = 32 prints the oracle's synchronous numbers; --gpus and -m learn say what they do not do yet"""
+    from sbm_bp_amd import synth
+    N, Q = 1600, 32
+    pairs, cin, cout = synth.planted_partition(N, Q, 12.0, 0.02, 21)
+    path = tmp_path / "q32.edgelist"
+    np.savetxt(path, pairs, fmt="%d")
+    sizes = synth.group_sizes(N, Q)
+    rc, out, err = run("-l", path, "-n", *sizes, "--epsilon_c", 0.02, 12.0, "-t", 1500, "-e", 1e-10, "-m", "infer", "-d", 0, "--precision", 15)
+    assert rc == 0, err
+    e, f, ov, niter = out.split("\n")[0].split()
+    og = orc.Graph.from_edges(pairs, N)
+    ob = orc.OracleBP(og, Q, 0)
+    ob.init_messages(0, None, synth.true_conf(N, Q), orc.Rng(0))
+    cab, na = orc.param_from_epsilon_c(N, Q, 0.02, 12.0)
+    ob.set_params(cab, na, 1.0)
+    ob.set_msg_form(True)
+    it, _ = ob.converge_sync(1e-10, 1500, 1.0)
+    assert it >= 0 and int(niter) == it
+    fo, _ = ob.free_energy(0)
+    eo, _ = ob.entropy(0)
+    assert abs(float(f) - fo) < 1e-9 * abs(fo) and abs(float(e) - eo) < 1e-8 * abs(eo) and abs(float(ov) - ob.overlap()) < 1e-9
+    rc, out, err = run("-l", path, "-n", *sizes, "--epsilon_c", 0.02, 12.0, "-m", "infer", "--gpus", 2)
+    assert rc == 1 and "Q in [2, 16]" in err
+    rc, out, err = run("-l", path, "-n", *sizes, "--epsilon_c", 0.02, 12.0, "-m", "learn")
+    assert rc == 1 and "up to Q = 16" in err
+    rc, out, err = run("-l", path, "-n", *([25] * 65), "--epsilon_c", 0.02, 12.0, "-m", "infer")
+    assert rc == 1 and "between 2 and 64" in err
+
+
 MATCHED = ["-l", DS, "-n", 500, 500, "--pa", 0.5, 0.5, "--cab", 5.4545454545454541, 0.54545454545454541, 5.4545454545454541,
            "-t", 5000, "-m", "infer", "-d", 0, "--precision", 15]
 

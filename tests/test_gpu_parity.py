@@ -210,7 +210,8 @@ def test_init_flags_2_and_3_run_against_the_oracle(S, orc, flag):
     _, obp, _ = oracle_from(orc, a)
     psi0, msg0 = bp.get_state()
     opsi0, omsg0 = obp.get_state()
-    assert np.array_equal(psi0, opsi0) and np.array_equal(msg0, omsg0)
+    # (messages live as records of Q-1 components on the device: the largest one comes back as 1 - sum, an ulp off at most)
+    assert np.array_equal(psi0, opsi0) and np.abs(msg0 - omsg0).max() < 4e-16
     clamped = np.flatnonzero(a["beliefs"] != -1)
     for _ in range(3):
         assert abs(bp.sweep(1, 1.0) - obp.sweep_sync(1.0)) < 1e-12

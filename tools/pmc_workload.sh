@@ -15,8 +15,9 @@ G3="FETCH_SIZE"
 G4="WRITE_SIZE"
 G5="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum"
 G6="TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum GRBM_GUI_ACTIVE"
+G7="SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES"   # matrix-core issue (the kernels of label counts above 16)
 i=0
-for G in "$G1" "$G2" "$G3" "$G4" "$G5" "$G6"; do
+for G in "$G1" "$G2" "$G3" "$G4" "$G5" "$G6" "$G7"; do
   i=$((i+1))
   echo "== pmc group $i: $G" >&2
   rocprofv3 --kernel-trace --pmc $G --output-format csv -d $OUT/g$i -o run -- python3 bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline --no-converge "$@" > $OUT/g$i.log 2>&1 || { echo "pmc group $i failed" >&2; tail -3 $OUT/g$i.log >&2; }

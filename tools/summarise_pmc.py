@@ -9,7 +9,7 @@ per = {}
 for f in glob.glob(os.path.join(OUT, "g*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
-        if not re.search(r"k_sweep|k_hub_frag|k_fold_finalize|k_fe_|k_em_|k_nonedge|k_row_sums|k_moments", name):
+        if not re.search(r"k_sweep|k_wsweep|k_wfinalize|k_wreduce|k_hub_frag|k_fold_finalize|k_fe_|k_em_|k_nonedge|k_row_sums|k_moments", name):
             continue
         k = re.sub(r"\(.*", "", name).replace("void sbmbp::", "")
         per.setdefault(k, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
@@ -35,6 +35,8 @@ for k, c in sorted(per.items()):
         d["valu_insts_per_wave"] = m["SQ_INSTS_VALU"] / m["SQ_WAVES"]
     if m.get("TCC_HIT_sum") is not None and m.get("TCC_MISS_sum") is not None and (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]) > 0:
         d["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
+    if m.get("SQ_INSTS_MFMA") is not None and m.get("SQ_WAVES"):
+        d["mfma_insts_per_wave"] = m["SQ_INSTS_MFMA"] / m["SQ_WAVES"]
     if "FETCH_SIZE" in m:
         d["fetch_bytes_as_counted"] = m["FETCH_SIZE"] * 1024.0
     if "WRITE_SIZE" in m:
