@@ -83,6 +83,11 @@ int sbmbp_param_from_direct(uint32_t n_vertices, uint32_t Q, const double *pa, c
 /* ---------------------------------------------------------------------------------------------
  * Engine life cycle. sbmbp_create replaces bp_allocate (belief_propagation.cpp:223-288): it
  * uploads the CSR and allocates messages/marginals in HBM. device < 0 selects the current device.
+ * Q = 2 .. SBMBP_MAX_Q (the reference has no cap, main.cpp:271). Up to 16 labels a lane owns a directed edge; above, an
+ * edge is spread over four lanes and W^T m runs on the matrix cores (csrc/kernels_wide.h): every entry point below works
+ * there too (converge / sweep / free energy / entropy / EM expectations / overlap / inference / learning, damping, beta,
+ * clamped rows, deg_corr_flag 0 and 1, the adaptive relaxation), except deg_corr_flag 2 and cab entries <= 0, which
+ * return SBMBP_ERR_UNSUPPORTED; the shard entry points and the multi-GPU driver take Q <= 16.
  * ------------------------------------------------------------------------------------------- */
 int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint32_t deg_corr_flag, int device);
 void sbmbp_destroy(sbmbp_engine_t *e);

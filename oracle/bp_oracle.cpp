@@ -553,24 +553,27 @@ struct ar_t {
     }
     // after sweep `it`: v = reported difference of kind `kind`, Sraw = unrelaxed sums of the new marginals. Returns true when
     // the run has converged. `was_psi`: the sweep ran in the marginal-gather form.
-    bool after_sweep(double v, int kind, const std::vector<double> &Sraw, bool was_psi) {
+    // `rf`: what a plain sweep from here would move the field term beta h/N by (0 while the field is not relaxed): a relaxed
+    // field lags its marginals, and the messages can stand still to within crit while it is still catching up.
+    bool after_sweep(double v, int kind, const std::vector<double> &Sraw, bool was_psi, double rf = 0.0) {
         bool conv = false, esc = false;
+        const bool field_ok = rf < crit;
         if (!on) {
-            if (kind == 1) conv = v < crit;
+            if (kind == 1) conv = v < crit && field_ok;
             else { hint(v); }
             return conv;
         }
         if (probing) {
             probing = false;
-            if (kind == 1 && v < crit) conv = true;
+            if (kind == 1 && v < crit && field_ok) conv = true;
             else if (v1 >= 0) {
                 const double one = kind == 1 ? v : v1, two = kind == 1 ? v1 : v;
-                if (two < 0.5 * one) { why = "P: probe"; esc_gen(); esc = true; }
+                if (two < 0.5 * one) { why = "P: probe"; if (gl < 1) gl = 1; esc_gen(); esc = true; }  // messages with period 2: damping answers that, a softer field does not
                 else { hold = 8; stall = 0; }
             }
         } else {
             if (kind == 1) {
-                if (v < crit) conv = true;
+                if (v < crit && field_ok) conv = true;
             } else hint(v);
             if (!conv && !esc) {
                 if (hold > 0) --hold;
@@ -651,8 +654,15 @@ int converge_sync(bp_t &s, double crit, unsigned max_iter, double damp, double *
         if (last_diff) *last_diff = d1;
         std::fill(Sraw.begin(), Sraw.end(), 0.0);
         for (uint32_t i = 0; i < s.N; ++i) { const double gi = gweight(s, i); for (uint32_t q = 0; q < Q; ++q) Sraw[q] += gi * s.psi[size_t(i) * Q + q]; }
+        double rf = 0.0;
+        if (s.field_mix < 1.0 && s.Sprev.size() == Q)  // s.Sprev: the sums this sweep's field was formed from
+            for (uint32_t q1 = 0; q1 < Q; ++q1) {
+                double acc = 0.0;
+                for (uint32_t q2 = 0; q2 < Q; ++q2) acc += s.cab[q2 * Q + q1] * (Sraw[q2] - s.Sprev[q2]);
+                rf = std::max(rf, std::fabs(acc) / s.N * s.beta);
+            }
         ar.sweep = it;
-        if (ar.after_sweep(v, kind, Sraw, was_psi)) { result = it; break; }
+        if (ar.after_sweep(v, kind, Sraw, was_psi, rf)) { result = it; break; }
     }
     s.ar_fl = ar.fl; s.ar_gl = ar.gl;
     s.field_mix = keep_mix;

@@ -907,14 +907,26 @@ int em_expect(sbmbp_engine *e, double *na_e, double *nna_e, double *cab_e) {
     std::vector<double> rs;
     CHK(row_sums(e, rs));
     const double *na = rs.data(), *nna = rs.data() + Q;
-    if (e->wide) {
-        if (cab_e) { set_error("the EM expectations of cab (-m learn) are implemented up to Q = 16"); return SBMBP_ERR_UNSUPPORTED; }
-        if (na_e) std::copy(na, na + Q, na_e);
-        if (nna_e) std::copy(nna, nna + Q, nna_e);
-        return SBMBP_OK;
-    }
     const uint32_t T = Q * (Q + 1) / 2;
     std::vector<double> tri(T);
+    if (e->wide) {  // Q > 16: the numerators as a labels x labels product over the edges on the matrix cores (k_wem)
+        if (cab_e) {
+            const uint32_t nbw = uint32_t(std::min<uint64_t>(1024, std::max<uint64_t>(1, (e->E2 + WCAP - 1) / WCAP)));
+            CHK(ensure_partials(e, size_t(nbw) * Q * Q));
+            CHK(ensure_small(e, size_t(Q) * Q));
+            DISPATCH_QT(Q, hipLaunchKernelGGL((k_wem<QT>), dim3(nbw), dim3(WTPB), 0, e->stream, e->d_rev, e->d_M[e->cur], uint64_t(e->E2),
+                                              e->d_Pw, int(Q), e->d_partials));
+            HIPCHK(hipGetLastError());
+            CHK(fold_matrix_to_device(e, nbw, Q * Q, e->d_small));
+            std::vector<double> G(size_t(Q) * Q);
+            HIPCHK(hipMemcpyAsync(G.data(), e->d_small, G.size() * 8, hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+            uint32_t t = 0;
+            for (uint32_t q1 = 0; q1 < Q; ++q1)
+                for (uint32_t q2 = q1; q2 < Q; ++q2, ++t)
+                    tri[t] = e->cab[q1 * Q + q2] * (q1 == q2 ? G[q1 * Q + q1] : G[q1 * Q + q2] + G[q2 * Q + q1]);
+        }
+    } else
     if (fused_ok(e) && Q <= 8) {
         // the numerators come out of the fused pass, which also leaves the free-energy terms the EM loop asks for next
         CHK(fused_pass(e, false, true));

@@ -838,6 +838,19 @@ __device__ __forceinline__ void finalize_update(dev_params *__restrict__ P, cons
         // what the sweep reported: 1 = the reference's 1-step difference (bp.cpp:1059-1063), 2 = a 2-step difference
         const int kind = md_exact ? (probe2 ? 2 : 1) : ((hinted && !exact) ? 2 : 1);
         bool conv = false, esc = false;
+        // A relaxed field lags its marginals: the messages can stand still to within crit while it is still catching up. rf =
+        // what a plain sweep from here would move the field term beta h/N by; the run has converged when that is below crit too.
+        double rf = 0.0;
+        if (have_prev && mix < 1.0) {
+#pragma unroll
+            for (int q1 = 0; q1 < Q; ++q1) {
+                double acc = 0.0;
+#pragma unroll
+                for (int q2 = 0; q2 < Q; ++q2) acc += cab[q2 * Q + q1] * (sums[q2] - Sold[q2]);
+                rf = fmax(rf, fabs(acc) * invN * beta);
+            }
+        }
+        const bool field_ok = rf < crit;
         auto reset_after = [&]() {
             hold = 6; stall = 0; v1 = v2 = -1.0; prev_hint = 0.0; probing = 0; armed = 0;
             wn = 0; wmin = 1e300; pmin = -1.0; nS = 0; sigc = 0; d1p = -1.0; holdS = 4;
@@ -867,18 +880,18 @@ __device__ __forceinline__ void finalize_update(dev_params *__restrict__ P, cons
             if (v < scale * crit) armed = 1;
         };
         if (!ar_on) {
-            if (kind == 1) conv = md < crit; else hint(md);
+            if (kind == 1) conv = md < crit && field_ok; else hint(md);
         } else if (probing) {  // (P) the probe's answer
             probing = 0;
-            if (kind == 1 && md < crit) conv = true;
+            if (kind == 1 && md < crit && field_ok) conv = true;
             else if (v1 >= 0.0) {
                 const double one = kind == 1 ? md : v1, two = kind == 1 ? v1 : md;
-                if (two < 0.5 * one) { esc_gen(); esc = true; }
+                if (two < 0.5 * one) { if (gl < 1) gl = 1; esc_gen(); esc = true; }  // messages with period 2: damping answers that, a softer field does not
                 else { hold = 8; stall = 0; }
             }
         } else {
             if (kind == 1) {
-                if (md < crit) conv = true;
+                if (md < crit && field_ok) conv = true;
             } else hint(md);
             if (!conv && !esc) {
                 if (hold > 0) --hold;

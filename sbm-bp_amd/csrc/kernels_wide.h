@@ -330,6 +330,14 @@ k_wfinalize(const double *__restrict__ partials, uint32_t n_part, int mode, dev_
             const double base_mix = P->ar_base_mix;
             double v1 = P->ar_v1, v2 = P->ar_v2, wmin = P->ar_wmin, pmin = P->ar_pmin, d1p = P->ar_d1p;
             bool conv = false, esc = false;
+            double rf = 0.0;  // the field gate of finalize_update
+            if (shp && mix < 1.0)
+                for (int q1 = 0; q1 < Q; ++q1) {
+                    double acc = 0.0;
+                    for (int q2 = 0; q2 < Q; ++q2) acc += Pw->cab[q2 * Q + q1] * (ssum[q2] - Pw->S[q2]);
+                    rf = fmax(rf, fabs(acc) * P->invN * P->beta);
+                }
+            const bool field_ok = rf < crit;
             auto reset_after = [&]() {
                 hold = 6; stall = 0; v1 = v2 = -1.0; probing = 0;
                 wn = 0; wmin = 1e300; pmin = -1.0; nS = 0; sigc = 0; d1p = -1.0; holdS = 4;
@@ -350,17 +358,17 @@ k_wfinalize(const double *__restrict__ partials, uint32_t n_part, int mode, dev_
                 else esc_gen();
             };
             if (!ar_on) {
-                conv = kind == 1 && md < crit;
+                conv = kind == 1 && md < crit && field_ok;
             } else if (probing) {
                 probing = 0;
-                if (kind == 1 && md < crit) conv = true;
+                if (kind == 1 && md < crit && field_ok) conv = true;
                 else if (v1 >= 0.0) {
                     const double one = kind == 1 ? md : v1, two = kind == 1 ? v1 : md;
-                    if (two < 0.5 * one) { esc_gen(); esc = true; }
+                    if (two < 0.5 * one) { if (gl < 1) gl = 1; esc_gen(); esc = true; }
                     else { hold = 8; stall = 0; }
                 }
             } else {
-                if (kind == 1 && md < crit) conv = true;
+                if (kind == 1 && md < crit && field_ok) conv = true;
                 if (!conv) {
                     if (hold > 0) --hold;
                     else {
@@ -722,6 +730,77 @@ k_wnonedge_exact(const double *__restrict__ psi, uint32_t n, int Q, const double
         if (want_entropy && num * den != 0.0) acc[1] += num / den;
     }
     block_reduce_store<NE_NP>(acc, 0.0, sred, partials + (size_t(blockIdx.y) * gridDim.x + blockIdx.x) * (NE_NP + 1));
+}
+
+// ------------------------------------------------------------------------------------------------
+// EM numerators for Q in 17 .. 64 (compute_cab_expect, bp.cpp:892-989): G[a][b] = sum_e m_in,e[a] m_out,e[b] / (2 norm_e) with
+// norm_e = m_in^T cab m_out; the host forms cab_expect[a][b] = cab[a][b] (G[a][b] + G[b][a]) (a != b), cab[a][a] G[a][a].
+// Purely per edge, so the edges are taken as a flat list, 64 per trip (one tile of 16 per wave). G is a labels x labels
+// matrix product over the EDGES: the trip's x = m_in and y = m_out / (2 norm) go to LDS as [edge][label] and every wave
+// accumulates its share of the 16 x 16 output tiles with v_mfma_f64_16x16x4_f64 (A: x^T, lane l holds x[edge 4 step + (l >> 4)]
+// [label 16 at + (l & 15)]; B: y likewise) over the 16 steps of a trip. A workgroup walks trips b, b + grid, ... and writes its
+// Q x Q sums once: partials[b Q Q + a Q + b'].
+// ------------------------------------------------------------------------------------------------
+template <int QT>
+__global__ void __launch_bounds__(WTPB)
+k_wem(const uint32_t *__restrict__ rev, const double *__restrict__ M, uint64_t n_edges, const dev_wide *__restrict__ Pw, int Q,
+      double *__restrict__ partials) {
+    constexpr int QP = 16 * QT, QS = 4 * QT, NT = QT * QT, TPW = (NT + 3) / 4;  // output tiles, tiles per wave
+    __shared__ double sx[WCAP * QP];
+    __shared__ double sy[WCAP * QP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, le_t = lane & 15, g = lane >> 4;
+    d4 acc[TPW];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) acc[u] = d4{0.0, 0.0, 0.0, 0.0};
+    const uint64_t n_trips = (n_edges + WCAP - 1) / WCAP;
+    for (uint64_t trip = blockIdx.x; trip < n_trips; trip += gridDim.x) {
+        const uint64_t k = trip * WCAP + uint64_t(wave * 16 + le_t);
+        const bool valid = k < n_edges;
+        const uint64_t kk = valid ? k : 0;
+        const uint32_t rk = rev[kk];
+        double mi[QS], mo[QS], c[QS], t1[QS];
+        wide_load<QS>(M, rk, Q, valid, mi);
+        wide_load<QS>(M, kk, Q, valid, mo);
+        wide_matvec<QT>(Pw->tC, mi, c);  // cab^T m_in
+#pragma unroll
+        for (int s = 0; s < QS; ++s) t1[s] = c[s] * mo[s];
+        const double norm = edge_sum<QS>(t1);
+        const double hin = valid ? 0.5 / norm : 0.0;
+        __syncthreads();  // the trip before has been consumed
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            sx[(wave * 16 + le_t) * QP + g + 4 * s] = mi[s];
+            sy[(wave * 16 + le_t) * QP + g + 4 * s] = mo[s] * hin;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const int tile = wave + 4 * u;  // wave-uniform
+            if (tile < NT) {
+                const int at = tile / QT, bt = tile - at * QT;
+#pragma unroll
+                for (int step = 0; step < WCAP / 4; ++step) {
+                    const double a = sx[(4 * step + g) * QP + 16 * at + le_t];
+                    const double b = sy[(4 * step + g) * QP + 16 * bt + le_t];
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[u], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // C/D layout: lane l, register r: row (l >> 4) + 4 r (label a = 16 at + row), column l & 15 (label b = 16 bt + column)
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const int tile = wave + 4 * u;
+        if (tile < NT) {
+            const int at = tile / QT, bt = tile - at * QT;
+            const double v[4] = {acc[u].x, acc[u].y, acc[u].z, acc[u].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = 16 * at + g + 4 * r, b = 16 * bt + le_t;
+                if (a < Q && b < Q) partials[size_t(blockIdx.x) * Q * Q + size_t(a) * Q + b] = v[r];
+            }
+        }
+    }
 }
 
 }  // namespace sbmbp

@@ -147,7 +147,7 @@ def test_reference_flags_only_converge_on_the_oscillating_hub_instance(gpus):
 @pytest.mark.gpu
 def test_more_than_sixteen_blocks(tmp_path, orc):
     """the reference has no cap on the number of blocks (main.cpp:271); bin/bp takes up to 64 (matrix-core kernels above 16):
-    -m infer at Q = 32 prints the oracle's synchronous numbers; --gpus and -m learn say what they do not do yet"""
+    -m infer at Q = 32 prints the oracle's synchronous numbers, -m learn runs; --gpus says what it does not do yet"""
     from sbm_bp_amd import synth
     N, Q = 1600, 32
     pairs, cin, cout = synth.planted_partition(N, Q, 12.0, 0.02, 21)
@@ -170,8 +170,8 @@ def test_more_than_sixteen_blocks(tmp_path, orc):
     assert abs(float(f) - fo) < 1e-9 * abs(fo) and abs(float(e) - eo) < 1e-8 * abs(eo) and abs(float(ov) - ob.overlap()) < 1e-9
     rc, out, err = run("-l", path, "-n", *sizes, "--epsilon_c", 0.02, 12.0, "-m", "infer", "--gpus", 2)
     assert rc == 1 and "Q in [2, 16]" in err
-    rc, out, err = run("-l", path, "-n", *sizes, "--epsilon_c", 0.02, 12.0, "-m", "learn")
-    assert rc == 1 and "up to Q = 16" in err
+    rc, out, err = run("-l", path, "-n", *sizes, "--epsilon_c", 0.02, 12.0, "-m", "learn", "-t", 30, "-d", 0)
+    assert rc == 0 and len(out.split()) == Q + Q * Q, err  # group fractions, then the learned cab (tests/test_gpu_wide.py pins the numbers)
     rc, out, err = run("-l", path, "-n", *([25] * 65), "--epsilon_c", 0.02, 12.0, "-m", "infer")
     assert rc == 1 and "between 2 and 64" in err
 

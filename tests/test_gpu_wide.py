@@ -80,9 +80,10 @@ def test_wide_sweeps_and_convergence_against_the_oracle(S, orc, Q, dc):
         bound = t["N"] * (t["cab"].max() / t["N"]) ** 3 / 6.0  # SURVEY A.4 truncation bound of order 2 (1e-8 and less from N = 1e5 on)
         assert abs(fp2[2] - fp[2]) < 4.0 * bound + 1e-9, (fp2[2], fp[2], bound)
         bp.set_nonedge_mode(0, 0)
-    na1, nna1, _ = bp.em_expectations(cab=False)
-    na2, nna2, _ = ob.em_expect()
+    na1, nna1, cab1 = bp.em_expectations()
+    na2, nna2, cab2 = ob.em_expect()
     assert np.abs(na1 - na2).max() < 1e-9 and np.abs(nna1 - nna2).max() < 1e-8
+    assert np.abs(cab1 - cab2).max() <= 1e-9 * max(1.0, np.abs(cab2).max())  # the numerators: a labels x labels product over the edges (k_wem)
     n1, l1 = bp.converge(1e-10, 600, 1.0)
     n2, l2 = ob.converge_sync(1e-10, 600, 1.0)
     assert n1 == n2, (n1, n2, l1, l2)  # the same sweep - or, on a hard instance, both at the limit with the same last difference
@@ -114,6 +115,34 @@ def test_wide_clamped_rows_and_device_initial_state(S, orc):
     p2, m2 = bp2.get_state()
     ob.set_state(p2, m2)
     assert ob.sweep_sync(1.0) < 1e-8
+
+
+def test_wide_learning_follows_the_oracle(S, orc):
+    """-m learn above Q = 16: the EM loop (BP runs, EM expectations through the matrix cores, free energy) step for step
+    against the oracle's synchronous EM run"""
+    from sbm_bp_amd import synth
+    N, Q = 600, 20
+    pairs, cin, cout = synth.planted_partition(N, Q, 14.0, 0.02, 33)
+    tc = synth.true_conf(N, Q)
+    na = np.array(synth.group_sizes(N, Q), dtype=np.uint32)
+    cab0 = synth.cab_matrix(Q, 0.85 * cin, 1.5 * cout)
+    g = S.Graph.from_edges(pairs, N)
+    bm = S.blockmodel_t(g, Q, 0)
+    bp = S.bp_basic()
+    bp.init_messages(bm, 0, None, tc, 3)
+    res = bp.learning(bm, S.bp_blockmodel_state(cab0, na), 1e-6, 40, 0.3, 1.0)
+    og = orc.Graph.from_edges(pairs, N)
+    ob = orc.OracleBP(og, Q, 0)
+    ob.init_messages(0, None, tc, orc.Rng(3))
+    ob.set_params(cab0, na, 1.0)
+    ob.set_msg_form(True)
+    steps, f = ob.learning(1e-6, 40, 0.3, 1.0, None, sync=True, series_K=0)
+    cab, na1 = bp.get_params()
+    ocab, ona = ob.get_params()
+    assert res.em_steps == steps, (res.em_steps, steps)
+    assert np.abs(na1.astype(np.int64) - ona.astype(np.int64)).max() <= 1
+    if list(na1) == list(ona):
+        assert np.abs(cab - ocab).max() < 1e-6 * np.abs(ocab).max() and abs(res.free_energy - f) < 1e-7 * max(1.0, abs(f))
 
 
 def test_wide_limits_fail_loudly(S):
