@@ -50,6 +50,7 @@ WORKLOADS = {
     "Q8dc": (1_000_000, 8, 8.0, 0.1, 1, 3),
     # label counts above 16: the matrix-core kernels (csrc/kernels_wide.h; message-gather form, full Q-component records)
     "Q32": (1_000_000, 32, 8.0, 0.1, 0, 5),
+    "Q48": (500_000, 48, 8.0, 0.1, 0, 7),
     "Q64": (500_000, 64, 8.0, 0.1, 0, 6),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec

@@ -43,7 +43,7 @@ def _hipcc():
 
 def build_lib(force=False, verbose=False):
     srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "dist.hip", "host_graph.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("kernels.h", "host_graph.h")] + [os.path.join(ROOT, "include", "sbmbp.h")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("kernels.h", "kernels_wide.h", "host_graph.h")] + [os.path.join(ROOT, "include", "sbmbp.h")]
     out = os.path.join(CSRC, "libsbmbp_hip.so")
     if force or _newer(out, deps):
         cmd = [_hipcc(), "-std=c++14", "-O3", "--offload-arch=" + ARCH, "-fPIC", "-shared", "-pthread", "-o", out] + srcs + ["-lrccl"]

@@ -239,6 +239,7 @@ int upload_params(sbmbp_engine *e, double crit, bool hinted = false) {
         }
         for (uint32_t q = 0; q < Q; ++q) { Wd->eta[q] = e->eta[q]; Wd->logeta[q] = std::log(e->eta[q]); }
         wide_tiles(Wd->W, int(Q), Wd->tW);
+        wide_tiles_v(Wd->W, int(Q), Wd->tWv);
         wide_tiles(Wd->cab, int(Q), Wd->tC);
         wide_tiles(cl.data(), int(Q), Wd->tCL);
         HIPCHK(hipMemcpyAsync(e->d_Pw, Wd.get(), sizeof(dev_wide), hipMemcpyHostToDevice, e->stream));

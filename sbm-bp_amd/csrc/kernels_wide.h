@@ -15,9 +15,15 @@
 // plus two shuffles (xor 16, xor 32). The A tiles of W are read from a tile-ordered copy in HBM (32 KB at Q = 64: L1 / L2
 // resident). Rows of any degree are handled inside the one sweep kernel: segments of up to WCAP edges keep their edge fields
 // in LDS; a longer row is walked twice in chunks of WCAP edges (products, then cavities with the fields recomputed).
+// The sweep kernel numbers the labels differently ("layout V", wide_label_v: two consecutive labels per lane and register pair,
+// so that records move in 16-byte accesses) - the product does not care as long as the A tiles use the same numbering.
 //
-// This path is correctness first: message-gather form only (every sweep reports the reference's 1-step difference), full
-// Q-component message records, every cab entry > 0, deg_corr_flag 0 or 1.
+// Message-gather form only (every sweep reports the reference's 1-step difference), full Q-component message records, every cab
+// entry > 0, deg_corr_flag 0 or 1. What the sweep kernel's time is made of (round 3): a workgroup is a chain
+// of dependent round trips (segment -> rev -> records -> product -> row phase -> cavities), so waves in flight decide: register
+// targets of 4 / 3 / 3 waves per SIMD for Q <= 32 / 48 / 64, every independent load requested before the first wait, 16-byte
+// record accesses, reciprocals instead of divisions. Measured and dropped: workgroups looping over segments with the W tiles
+// in registers or in LDS (fewer waves in flight cost more than the L2 traffic of the tiles saves).
 #ifndef SBMBP_KERNELS_WIDE_H
 #define SBMBP_KERNELS_WIDE_H
 
@@ -25,6 +31,18 @@
 
 namespace sbmbp {
 
+#ifndef SBMBP_WIDE_PAD
+#define SBMBP_WIDE_PAD 8          // doubles added to the LDS row stride of k_wsweep
+#endif
+#ifndef SBMBP_WIDE_WAVES2
+#define SBMBP_WIDE_WAVES2 4       // waves per SIMD the register allocation of k_wsweep<QT> aims for, QT = 2 / 3 / 4
+#endif
+#ifndef SBMBP_WIDE_WAVES3
+#define SBMBP_WIDE_WAVES3 3
+#endif
+#ifndef SBMBP_WIDE_WAVES4
+#define SBMBP_WIDE_WAVES4 3
+#endif
 constexpr int WQ = 64;     // largest label count
 constexpr int WCAP = 64;   // directed edges per segment (4 tiles of 16, one per wave)
 constexpr int WRCAP = 16;  // rows per segment
@@ -40,6 +58,7 @@ struct dev_wide {
     double arS1[WQ], arS2[WQ];  // raw field sums of the last two sweeps (adaptive relaxation, signature F)
     // tile-ordered copies for the A operand (wide_tiles): W, cab, cab * log cab
     double tW[WQ * WQ], tC[WQ * WQ], tCL[WQ * WQ];
+    double tWv[WQ * WQ];     // W in the tile order of layout V (k_wsweep)
 };
 
 // T[(rt * QS + s) * 64 + l] = Wm[(4 s + (l >> 4)) * Q + 16 rt + (l & 15)], zero outside the Q x Q matrix
@@ -49,6 +68,22 @@ __host__ inline void wide_tiles(const double *Wm, int Q, double *T) {
         for (int s = 0; s < QS; ++s)
             for (int l = 0; l < 64; ++l) {
                 const int t = 4 * s + (l >> 4), q = 16 * rt + (l & 15);
+                T[(rt * QS + s) * 64 + l] = (t < Q && q < Q) ? Wm[t * Q + q] : 0.0;
+            }
+}
+
+// Layout V (k_wsweep only): lane group g, register s holds label 8 (s >> 1) + 2 g + (s & 1) - the four lanes of an edge cover 64
+// consecutive bytes of its record with one 16-byte access each. The matrix product does not care how the labels are numbered as
+// long as the A tiles use the same numbering for their columns (operand registers) and rows (result registers):
+__host__ __device__ inline int wide_label_v(int g, int s) { return 8 * (s >> 1) + 2 * g + (s & 1); }
+__host__ inline void wide_tiles_v(const double *Wm, int Q, double *T) {
+    const int QT = (Q + 15) / 16, QS = 4 * QT;
+    for (int rt = 0; rt < QT; ++rt)
+        for (int s = 0; s < QS; ++s)
+            for (int l = 0; l < 64; ++l) {
+                const int i = l & 15, k = l >> 4;                         // A[row i][column k] of the (rt, s) tile
+                const int q = wide_label_v(i & 3, (i >> 2) + 4 * rt);     // result row i = g + 4 r lands in register r + 4 rt of lane group g
+                const int t = wide_label_v(k, s);
                 T[(rt * QS + s) * 64 + l] = (t < Q && q < Q) ? Wm[t * Q + q] : 0.0;
             }
 }
@@ -85,34 +120,72 @@ template <int QS> __device__ __forceinline__ void wide_load(const double *__rest
     for (int s = 0; s < QS; ++s) { const int t = g + 4 * s; v[s] = (valid && t < Q) ? M[k * size_t(Q) + t] : 0.0; }
 }
 
+// layout V: 16-byte loads when the records are 16-byte aligned (Q even)
+template <int QS> __device__ __forceinline__ void wide_load_v(const double *__restrict__ M, size_t k, int Q, bool valid, double (&v)[QS]) {
+    const int g = (threadIdx.x & 63) >> 4;
+    if ((Q & 1) == 0) {
+#pragma unroll
+        for (int p = 0; p < QS / 2; ++p) {
+            const int t = 8 * p + 2 * g;
+            double2 x = make_double2(0.0, 0.0);
+            if (valid && t < Q) x = *reinterpret_cast<const double2 *>(M + k * size_t(Q) + t);
+            v[2 * p] = x.x;
+            v[2 * p + 1] = x.y;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < QS; ++s) { const int t = wide_label_v(g, s); v[s] = (valid && t < Q) ? M[k * size_t(Q) + t] : 0.0; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // One synchronous sweep (message-gather form), Q in 17 .. 64. Same equations, partial records and convergence bookkeeping as
 // k_sweep: partials[b (Q+1) + q] = sum_rows g_i psi_i[q], slot Q = max |m_new - m_old| (1-step; the adaptive relaxation's
 // probe: 2-step against the slot being overwritten).
 // ------------------------------------------------------------------------------------------------
 template <int QT>
-__global__ void __launch_bounds__(WTPB)
+__global__ void __launch_bounds__(WTPB) __attribute__((amdgpu_waves_per_eu(QT == 2 ? SBMBP_WIDE_WAVES2 : QT == 3 ? SBMBP_WIDE_WAVES3 : SBMBP_WIDE_WAVES4)))
 k_wsweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const double *__restrict__ Mold, double *__restrict__ Mnew,
          const double *__restrict__ psi_old, double *__restrict__ psi_new, const int32_t *__restrict__ clamp,
          const uint32_t *__restrict__ blk_row, const uint32_t *__restrict__ blk_e0, const dev_params *__restrict__ P,
          const dev_wide *__restrict__ Pw, int Q, int dc, double damp, double *__restrict__ partials) {
     constexpr int QP = 16 * QT, QS = 4 * QT;
-    __shared__ double sb[WCAP * QP];     // edge fields of the segment / chunk
-    __shared__ double sA[WRCAP * QP];    // per row: log weights, then the normalised marginal
+    constexpr int QPP = QP + SBMBP_WIDE_PAD;  // LDS row stride: the 16 edges of a tile land 64 bytes apart modulo the banks
+    __shared__ double sb[WCAP * QPP];     // edge fields of the segment / chunk
+    __shared__ double sA[WRCAP * QPP];    // per row: log weights, then the normalised marginal
     __shared__ uint32_t srp[WRCAP + 1];
     __shared__ uint16_t srow[WCAP];
     __shared__ uint8_t sfl[WRCAP];
     __shared__ double smd[WTPB / 64];
-    if (P->stop) return;
+    __shared__ double sle[WQ], shn[WQ];  // log eta, h / N
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, le_t = lane & 15, g = lane >> 4;
     const uint32_t bid = blockIdx.x;
-    const uint32_t r0 = blk_row[bid], r1 = blk_row[bid + 1], e0 = blk_e0[bid];
-    const int nrows = int(r1 - r0), ne = int(blk_e0[bid + 1] - e0);
-    const int probe2 = P->ar_probe2;
-    damp *= P->damp_auto;
-    const double beta = P->beta;
+    // everything that does not depend on other loads is requested before the first wait: a workgroup is a chain of dependent
+    // round trips (segment -> rev -> message records), and each one it saves is a tenth of its lifetime
+    const int stop = P->stop, probe2 = P->ar_probe2;
+    const double damp_auto = P->damp_auto, beta = P->beta;
+    const uint32_t r0 = blk_row[bid], r1 = blk_row[bid + 1], e0 = blk_e0[bid], e1 = blk_e0[bid + 1];
+    if (tid < Q) { sle[tid] = Pw->logeta[tid]; shn[tid] = Pw->hN[tid]; }
+    if (stop) return;
+    damp *= damp_auto;
+    const double *__restrict__ Atiles = Pw->tWv;
+    auto lab = [&](int s) { return wide_label_v(g, s); };  // the label in register s of this lane
+    const int nrows = int(r1 - r0), ne = int(e1 - e0);
     double md = 0.0;
 
+    auto matvec = [&](const double (&v)[QS], double (&out)[QS]) {
+#pragma unroll
+        for (int rt = 0; rt < QT; ++rt) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < QS; ++s)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Atiles[(rt * QS + s) * 64 + lane], v[s], acc, 0, 0, 0);
+            out[4 * rt + 0] = acc.x;
+            out[4 * rt + 1] = acc.y;
+            out[4 * rt + 2] = acc.z;
+            out[4 * rt + 3] = acc.w;
+        }
+    };
     // edge fields of the 16 edges [base, base + 16) of this wave's tile: b = W^T m_in; mo = the edge's own old message
     auto tile_fields = [&](int base, double (&mo)[QS], double (&b)[QS], bool &valid, uint32_t &k) {
         const int le = base + le_t;
@@ -120,48 +193,62 @@ k_wsweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev,
         k = e0 + uint32_t(valid ? le : 0);
         const uint32_t rk = (ne > 0) ? rev[k] : 0u;
         double mi[QS];
-        wide_load<QS>(Mold, rk, Q, valid, mi);
-        wide_load<QS>(Mold, k, Q, valid, mo);
-        wide_matvec<QT>(Pw->tW, mi, b);
+        wide_load_v<QS>(Mold, rk, Q, valid, mi);
+        wide_load_v<QS>(Mold, k, Q, valid, mo);
+        matvec(mi, b);
     };
     // new message of one edge from the row's normalised marginal A (LDS) and its field b; stores it, returns nothing
     auto cavity = [&](const double *Arow, const double (&mo)[QS], const double (&b)[QS], bool valid, uint32_t k, bool clamped) {
         double cav[QS];
 #pragma unroll
-        for (int s = 0; s < QS; ++s) { const int t = g + 4 * s; cav[s] = (valid && t < Q) ? Arow[t] / b[s] : 0.0; }
+        for (int s = 0; s < QS; ++s) {  // psi / b with a refined hardware reciprocal (QS divisions per lane were a tenth of the kernel's vector instructions)
+            const int t = lab(s);
+            double rb = __builtin_amdgcn_rcp(b[s]);
+            rb = fma(fma(-b[s], rb, 1.0), rb, rb);
+            rb = fma(fma(-b[s], rb, 1.0), rb, rb);
+            cav[s] = (valid && t < Q) ? Arow[t] * rb : 0.0;
+        }
         const double tot = edge_sum<QS>(cav);
         const double inv = 1.0 / tot;
         if (valid) {
+            double outv[QS];
 #pragma unroll
             for (int s = 0; s < QS; ++s) {
-                const int t = g + 4 * s;
-                if (t < Q) {
-                    double out = mo[s];
-                    if (!clamped) {
-                        const double nv = cav[s] * inv;
-                        out = damp * nv + (1.0 - damp) * mo[s];
-                        const double ref = probe2 ? Mnew[size_t(k) * Q + t] : mo[s];
-                        md = nanmax(md, probe2 ? fabs(ref - out) / damp : fabs(ref - nv));
-                    }
-                    Mnew[size_t(k) * Q + t] = out;
+                const int t = lab(s);
+                outv[s] = mo[s];
+                if (t < Q && !clamped) {
+                    const double nv = cav[s] * inv;
+                    outv[s] = damp * nv + (1.0 - damp) * mo[s];
+                    const double ref = probe2 ? Mnew[size_t(k) * Q + t] : mo[s];
+                    md = nanmax(md, probe2 ? fabs(ref - outv[s]) / damp : fabs(ref - nv));
                 }
+            }
+            if ((Q & 1) == 0) {
+#pragma unroll
+                for (int p = 0; p < QS / 2; ++p) {
+                    const int t = 8 * p + 2 * g;
+                    if (t < Q) *reinterpret_cast<double2 *>(Mnew + size_t(k) * Q + t) = make_double2(outv[2 * p], outv[2 * p + 1]);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < QS; ++s) { const int t = lab(s); if (t < Q) Mnew[size_t(k) * Q + t] = outv[s]; }
             }
         }
     };
     // row r of the segment: log weights in sA[r] -> normalised marginal in sA[r] and in psi_new (16 lanes per row: j = lane & 15)
     auto normalise_row = [&](int r, uint32_t row, int j) {
         double mx = -1.0e300;
-        for (int q = j; q < Q; q += 16) mx = fmax(mx, sA[r * QP + q]);
+        for (int q = j; q < Q; q += 16) mx = fmax(mx, sA[r * QPP + q]);
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 16));
         double sum = 0.0;
-        for (int q = j; q < Q; q += 16) sum += exp(sA[r * QP + q] - mx);
+        for (int q = j; q < Q; q += 16) sum += exp(sA[r * QPP + q] - mx);
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
         const double inv = 1.0 / sum;
         for (int q = j; q < Q; q += 16) {
-            const double pv = exp(sA[r * QP + q] - mx) * inv;
-            sA[r * QP + q] = pv;
+            const double pv = exp(sA[r * QPP + q] - mx) * inv;
+            sA[r * QPP + q] = pv;
             psi_new[size_t(row) * Q + q] = pv;
         }
     };
@@ -175,7 +262,7 @@ k_wsweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev,
         tile_fields(wave * 16, mo, b, valid, k);
         if (valid) {
 #pragma unroll
-            for (int s = 0; s < QS; ++s) sb[(wave * 16 + le_t) * QP + g + 4 * s] = b[s];
+            for (int s = 0; s < QS; ++s) sb[(wave * 16 + le_t) * QPP + lab(s)] = b[s];
         }
         __syncthreads();
         for (int r = tid; r < nrows; r += WTPB) {
@@ -190,11 +277,11 @@ k_wsweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev,
             double a = 1.0;
             int ex = 0;
             for (int e = es; e < ee; ++e) {
-                a *= sb[e * QP + q];
+                a *= sb[e * QPP + q];
                 if (((e - es) & 3) == 3) { int kx; a = frexp(a, &kx); ex += kx; }
             }
             const double fld = dc ? double(ee - es) : beta;
-            sA[r * QP + q] = log(a) + double(ex) * 0.6931471805599453 + Pw->logeta[q] - fld * Pw->hN[q];
+            sA[r * QPP + q] = log(a) + double(ex) * 0.6931471805599453 + sle[q] - fld * shn[q];
         }
         __syncthreads();
         {   // 16 lanes per row: 256 threads cover the WRCAP rows in one pass
@@ -203,7 +290,7 @@ k_wsweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev,
                 if (sfl[r]) {  // clamped row: marginal (and out-messages, below) stay as initialised (bp.cpp:1115-1124)
                     for (int q = j; q < Q; q += 16) {
                         const double pv = psi_old[size_t(r0 + r) * Q + q];
-                        sA[r * QP + q] = pv;
+                        sA[r * QPP + q] = pv;
                         psi_new[size_t(r0 + r) * Q + q] = pv;
                     }
                 } else {
@@ -214,11 +301,11 @@ k_wsweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev,
         __syncthreads();
         if (tid < Q) {  // field sums of the segment, rows in order
             double S = 0.0;
-            for (int r = 0; r < nrows; ++r) S += (dc ? double(srp[r + 1] - srp[r]) : 1.0) * sA[r * QP + tid];
+            for (int r = 0; r < nrows; ++r) S += (dc ? double(srp[r + 1] - srp[r]) : 1.0) * sA[r * QPP + tid];
             partials[size_t(bid) * (Q + 1) + tid] = S;
         }
         const int rr = valid ? int(srow[wave * 16 + le_t]) : 0;
-        cavity(&sA[rr * QP], mo, b, valid, k, valid && sfl[rr] != 0);
+        cavity(&sA[rr * QPP], mo, b, valid, k, valid && sfl[rr] != 0);
     } else {
         // ---- one long row (nrows == 1), walked twice in chunks of WCAP edges
         const bool clamped = clamp != nullptr && clamp[r0] != -1;
@@ -233,18 +320,18 @@ k_wsweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev,
                 __syncthreads();  // the chunk before has been multiplied in
                 if (valid) {
 #pragma unroll
-                    for (int s = 0; s < QS; ++s) sb[(wave * 16 + le_t) * QP + g + 4 * s] = b[s];
+                    for (int s = 0; s < QS; ++s) sb[(wave * 16 + le_t) * QPP + lab(s)] = b[s];
                 }
                 __syncthreads();
                 if (tid < Q) {
                     const int cnt = min(WCAP, ne - c0);
                     for (int e = 0; e < cnt; ++e) {
-                        a *= sb[e * QP + tid];
+                        a *= sb[e * QPP + tid];
                         if ((e & 3) == 3) { int kx; a = frexp(a, &kx); ex += kx; }
                     }
                 }
             }
-            if (tid < Q) sA[tid] = log(a) + double(ex) * 0.6931471805599453 + Pw->logeta[tid] - (dc ? double(ne) : beta) * Pw->hN[tid];
+            if (tid < Q) sA[tid] = log(a) + double(ex) * 0.6931471805599453 + sle[tid] - (dc ? double(ne) : beta) * shn[tid];
             __syncthreads();
             if (tid < 16) normalise_row(0, r0, tid);
         } else if (tid < 16) {

@@ -21,6 +21,12 @@ for WL in C3 C2 C4 C5; do
   echo "== rocprofv3 stats $WL" >&2
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$WL -o run -- python3 bench.py --workload $WL --no-cpu-baseline --no-converge > $OUT/stats_$WL.log 2>&1 || exit 1
 done
+echo "== label counts above 16 (matrix-core kernels): bench lines, kernel stats and counters at Q = 32" >&2
+for WL in Q32 Q48 Q64; do
+  python3 bench.py --workload $WL --no-cpu-baseline --converge > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err || echo "bench $WL failed" >&2
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_Q32 -o run -- python3 bench.py --workload Q32 --no-cpu-baseline --no-converge > $OUT/stats_Q32.log 2>&1 || echo "stats Q32 failed" >&2
+tools/pmc_workload.sh $R Q64 > $OUT/pmc_Q64.log 2>&1 || echo "pmc Q64 failed" >&2
 echo "== bench C3, 200 timed steps" >&2
 python3 bench.py --workload C3 --steps 200 --warmup 5 --no-cpu-baseline --no-converge > $OUT/bench_C3_200steps.json 2> $OUT/bench_C3_200steps.err || exit 1
 echo "== bench C3 --gather messages" >&2
