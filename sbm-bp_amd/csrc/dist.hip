@@ -25,6 +25,7 @@
 #include "host_graph.h"
 
 using sbmbp::set_error;
+using sbmbp::arg_error;
 typedef uint32_t u32;
 typedef uint64_t u64;
 
@@ -480,7 +481,7 @@ int comm_allreduce(sbmbp_comm *c, double *buf, size_t n, int op, hipStream_t str
 extern "C" {
 
 int sbmbp_comm_unique_id(void *id_out) {
-    if (!id_out) return SBMBP_ERR_ARG;
+    if (!id_out) return arg_error(__func__, __LINE__);
     static_assert(2 * sizeof(ncclUniqueId) <= SBMBP_COMM_ID_BYTES, "SBMBP_COMM_ID_BYTES too small");
     ncclUniqueId ids[2];
     NCCLCHK(ncclGetUniqueId(&ids[0]));
@@ -491,7 +492,7 @@ int sbmbp_comm_unique_id(void *id_out) {
 }
 
 int sbmbp_comm_init_rank(sbmbp_comm_t **out, const void *id, int n_ranks, int rank, int device) {
-    if (!out || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return SBMBP_ERR_ARG;
+    if (!out || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return arg_error(__func__, __LINE__);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device visible"); return SBMBP_ERR_NODEVICE; }
     if (device >= 0) HIPCHK(hipSetDevice(device));
@@ -518,7 +519,7 @@ int sbmbp_comm_init_rank(sbmbp_comm_t **out, const void *id, int n_ranks, int ra
 }
 
 int sbmbp_comm_init_local(sbmbp_comm_t **out, int n_ranks) {
-    if (!out || n_ranks < 1) return SBMBP_ERR_ARG;
+    if (!out || n_ranks < 1) return arg_error(__func__, __LINE__);
     auto g = std::make_shared<local_group>();
     g->n = n_ranks;
     if (const char *t = std::getenv("SBMBP_LOCAL_TIMEOUT_S")) g->timeout_s = std::max(1.0, std::atof(t));
@@ -535,7 +536,7 @@ int sbmbp_comm_init_local(sbmbp_comm_t **out, int n_ranks) {
 }
 
 int sbmbp_comm_init_callbacks(sbmbp_comm_t **out, int n_ranks, int rank, const sbmbp_comm_callbacks *cb) {
-    if (!out || !cb || !cb->exchange || !cb->allgather || !cb->allreduce || n_ranks < 1 || rank < 0 || rank >= n_ranks) return SBMBP_ERR_ARG;
+    if (!out || !cb || !cb->exchange || !cb->allgather || !cb->allreduce || n_ranks < 1 || rank < 0 || rank >= n_ranks) return arg_error(__func__, __LINE__);
     auto *c = new sbmbp_comm();
     c->kind = 2;
     c->rank = rank;
@@ -546,7 +547,7 @@ int sbmbp_comm_init_callbacks(sbmbp_comm_t **out, int n_ranks, int rank, const s
 }
 
 int sbmbp_comm_init_null(sbmbp_comm_t **out, int n_ranks, int rank) {
-    if (!out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return SBMBP_ERR_ARG;
+    if (!out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return arg_error(__func__, __LINE__);
     auto *c = new sbmbp_comm();
     c->kind = 3;
     c->rank = rank;
@@ -992,7 +993,7 @@ extern "C" {
 
 int sbmbp_dist_create(sbmbp_dist_t **out, sbmbp_comm_t *comm, const sbmbp_graph_t *g, uint32_t Q, uint32_t dc, int device,
                       uint32_t n_chunks) {
-    if (!out || !comm || !g) return SBMBP_ERR_ARG;
+    if (!out || !comm || !g) return arg_error(__func__, __LINE__);
     if (Q < 2 || Q > 16) { set_error("the multi-GPU driver handles Q in [2, 16]"); return SBMBP_ERR_UNSUPPORTED; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device visible; the engine has no CPU fallback"); return SBMBP_ERR_NODEVICE; }
@@ -1123,7 +1124,7 @@ void sbmbp_dist_destroy(sbmbp_dist_t *d) {
 }
 
 int sbmbp_dist_info(const sbmbp_dist_t *d, sbmbp_dist_info_t *out) {
-    if (!d || !out) return SBMBP_ERR_ARG;
+    if (!d || !out) return arg_error(__func__, __LINE__);
     const shard_plan &P = d->plan;
     out->rank = d->rank;
     out->world = d->world;
@@ -1144,7 +1145,7 @@ int sbmbp_dist_info(const sbmbp_dist_t *d, sbmbp_dist_info_t *out) {
 }
 
 int sbmbp_dist_peer_rows(const sbmbp_dist_t *d, uint64_t *send_rows, uint64_t *recv_rows) {
-    if (!d) return SBMBP_ERR_ARG;
+    if (!d) return arg_error(__func__, __LINE__);
     if (send_rows) std::copy(d->plan.send_counts.begin(), d->plan.send_counts.end(), send_rows);
     if (recv_rows) std::copy(d->plan.recv_counts.begin(), d->plan.recv_counts.end(), recv_rows);
     return SBMBP_OK;
@@ -1154,7 +1155,7 @@ int sbmbp_dist_peer_rows(const sbmbp_dist_t *d, uint64_t *send_rows, uint64_t *r
 // rank (same seed, same order) and each keeps the rows and out-messages it owns
 int sbmbp_dist_init_messages(sbmbp_dist_t *d, uint32_t flag, const int32_t *conf, const uint32_t *true_conf, uint32_t seed,
                              int conditional) {
-    if (!d || !true_conf) return SBMBP_ERR_ARG;
+    if (!d || !true_conf) return arg_error(__func__, __LINE__);
     const sbmbp_graph_t *g = d->graph;
     if (flag >= 4) { set_error("bp_messages_init_flag must be < 4"); return SBMBP_ERR_ARG; }  // assert at bp.cpp:106
     if (flag != 0 && !conf) { set_error("init flag != 0 needs a conf vector"); return SBMBP_ERR_ARG; }
@@ -1189,7 +1190,7 @@ int sbmbp_dist_init_messages(sbmbp_dist_t *d, uint32_t flag, const int32_t *conf
 }
 
 int sbmbp_dist_init_messages_device(sbmbp_dist_t *d, uint64_t seed, const uint32_t *true_conf) {
-    if (!d || !true_conf) return SBMBP_ERR_ARG;
+    if (!d || !true_conf) return arg_error(__func__, __LINE__);
     device_guard guard(d->device);
     CHK(sbmbp_init_messages_device(d->eng, seed, true_conf + d->plan.row0));
     d->have_state = true;
@@ -1198,7 +1199,7 @@ int sbmbp_dist_init_messages_device(sbmbp_dist_t *d, uint64_t seed, const uint32
 }
 
 int sbmbp_dist_set_state(sbmbp_dist_t *d, const double *psi_own, const double *msg_own) {
-    if (!d) return SBMBP_ERR_ARG;
+    if (!d) return arg_error(__func__, __LINE__);
     device_guard guard(d->device);
     CHK(sbmbp_set_state(d->eng, psi_own, msg_own));
     if (psi_own && (msg_own || d->plan.n_edges == 0)) d->have_state = true;
@@ -1207,14 +1208,14 @@ int sbmbp_dist_set_state(sbmbp_dist_t *d, const double *psi_own, const double *m
 }
 
 int sbmbp_dist_get_state(sbmbp_dist_t *d, double *psi_own, double *msg_own) {
-    if (!d) return SBMBP_ERR_ARG;
+    if (!d) return arg_error(__func__, __LINE__);
     device_guard guard(d->device);
     HIPCHK(hipStreamSynchronize(d->s_comm));
     return sbmbp_get_state(d->eng, psi_own, msg_own);
 }
 
 int sbmbp_dist_gather_marginals(sbmbp_dist_t *d, double *psi_all) {
-    if (!d || !psi_all) return SBMBP_ERR_ARG;
+    if (!d || !psi_all) return arg_error(__func__, __LINE__);
     device_guard guard(d->device);
     const u32 N = d->plan.n_global, Q = d->Q;
     double *tab = nullptr;
@@ -1234,7 +1235,7 @@ int sbmbp_dist_gather_marginals(sbmbp_dist_t *d, double *psi_all) {
 }
 
 int sbmbp_dist_set_params(sbmbp_dist_t *d, const double *cab, const uint32_t *na, double beta) {
-    if (!d || !cab || !na) return SBMBP_ERR_ARG;
+    if (!d || !cab || !na) return arg_error(__func__, __LINE__);
     device_guard guard(d->device);
     return apply_params(d, cab, na, beta);
 }
@@ -1247,42 +1248,42 @@ int sbmbp_dist_get_params(sbmbp_dist_t *d, double *cab, uint32_t *na) {
 }
 
 int sbmbp_dist_set_schedule(sbmbp_dist_t *d, double field_mix, uint32_t check_every) {
-    if (!d || !(field_mix > 0.0) || field_mix > 1.0 || check_every < 1) return SBMBP_ERR_ARG;
+    if (!d || !(field_mix > 0.0) || field_mix > 1.0 || check_every < 1) return arg_error(__func__, __LINE__);
     d->field_mix = field_mix;
     d->check_every = check_every;
     return SBMBP_OK;
 }
 
 int sbmbp_dist_set_learning_schedule(sbmbp_dist_t *d, double field_mix, double snap) {
-    if (!d || !(field_mix > 0.0) || field_mix > 1.0 || !(snap >= 0.0)) return SBMBP_ERR_ARG;
+    if (!d || !(field_mix > 0.0) || field_mix > 1.0 || !(snap >= 0.0)) return arg_error(__func__, __LINE__);
     d->learn_field_mix = field_mix;
     d->learn_snap = snap;
     return SBMBP_OK;
 }
 
 int sbmbp_dist_set_gather_mode(sbmbp_dist_t *d, int mode) {
-    if (!d || mode < 0 || mode > 1) return SBMBP_ERR_ARG;
+    if (!d || mode < 0 || mode > 1) return arg_error(__func__, __LINE__);
     d->gather_mode = mode;
     return SBMBP_OK;
 }
 
 int sbmbp_dist_set_auto_relax(sbmbp_dist_t *d, int on) {
-    if (!d) return SBMBP_ERR_ARG;
+    if (!d) return arg_error(__func__, __LINE__);
     return sbmbp_set_auto_relax(d->eng, on);
 }
 int sbmbp_dist_get_relaxation(const sbmbp_dist_t *d, int *field_level, int *generic_level) {
-    if (!d) return SBMBP_ERR_ARG;
+    if (!d) return arg_error(__func__, __LINE__);
     return sbmbp_get_relaxation(d->eng, field_level, generic_level, nullptr, nullptr);
 }
 
 int sbmbp_dist_converge(sbmbp_dist_t *d, double crit, uint32_t max_sweeps, double damping, int *niter, double *last) {
-    if (!d) return SBMBP_ERR_ARG;
+    if (!d) return arg_error(__func__, __LINE__);
     device_guard guard(d->device);
     return run(d, crit, max_sweeps, damping, niter, last);
 }
 
 int sbmbp_dist_sweep(sbmbp_dist_t *d, double damping, uint32_t n_sweeps, double *last) {
-    if (!d) return SBMBP_ERR_ARG;
+    if (!d) return arg_error(__func__, __LINE__);
     device_guard guard(d->device);
     const u32 keep = d->check_every;
     d->check_every = std::max<u32>(keep, 64);  // no convergence test: sync rarely
@@ -1292,7 +1293,7 @@ int sbmbp_dist_sweep(sbmbp_dist_t *d, double damping, uint32_t n_sweeps, double 
 }
 
 int sbmbp_dist_free_energy(sbmbp_dist_t *d, double *f, double *parts) {
-    if (!d) return SBMBP_ERR_ARG;
+    if (!d) return arg_error(__func__, __LINE__);
     device_guard guard(d->device);
     double t[6];
     CHK(fe_terms(d, false, t));
@@ -1302,7 +1303,7 @@ int sbmbp_dist_free_energy(sbmbp_dist_t *d, double *f, double *parts) {
 }
 
 int sbmbp_dist_entropy(sbmbp_dist_t *d, double *ent, double *parts) {
-    if (!d) return SBMBP_ERR_ARG;
+    if (!d) return arg_error(__func__, __LINE__);
     device_guard guard(d->device);
     if (d->dc != 0) {  // the reference evaluates 0/0 in e_site for deg_corr_flag != 0 (bp.cpp:550-556)
         const double nan = std::nan("");
@@ -1318,25 +1319,25 @@ int sbmbp_dist_entropy(sbmbp_dist_t *d, double *ent, double *parts) {
 }
 
 int sbmbp_dist_em_expectations(sbmbp_dist_t *d, double *na_e, double *nna_e, double *cab_e) {
-    if (!d) return SBMBP_ERR_ARG;
+    if (!d) return arg_error(__func__, __LINE__);
     device_guard guard(d->device);
     return em_expect(d, na_e, nna_e, cab_e);
 }
 
 int sbmbp_dist_confusion(sbmbp_dist_t *d, double *C) {
-    if (!d || !C) return SBMBP_ERR_ARG;
+    if (!d || !C) return arg_error(__func__, __LINE__);
     device_guard guard(d->device);
     return overlap_of(d, nullptr, C);
 }
 
 int sbmbp_dist_overlap(sbmbp_dist_t *d, double *ov) {
-    if (!d || !ov) return SBMBP_ERR_ARG;
+    if (!d || !ov) return arg_error(__func__, __LINE__);
     device_guard guard(d->device);
     return overlap_of(d, ov, nullptr);
 }
 
 int sbmbp_dist_inference(sbmbp_dist_t *d, float conv_crit, uint32_t time_conv, float dumping_rate, sbmbp_infer_result *out) {
-    if (!d || !out) return SBMBP_ERR_ARG;
+    if (!d || !out) return arg_error(__func__, __LINE__);
     device_guard guard(d->device);
     // belief_propagation::inference (bp.cpp:77-99); crit and damping arrive as float, compared as double (:406)
     CHK(run(d, double(conv_crit), time_conv, double(dumping_rate), &out->niter, &out->last_maxdiff));
@@ -1349,7 +1350,7 @@ int sbmbp_dist_inference(sbmbp_dist_t *d, float conv_crit, uint32_t time_conv, f
 
 int sbmbp_dist_learning(sbmbp_dist_t *d, float learning_conv_crit, uint32_t learning_max_time, float learning_rate, float dumping_rate,
                         sbmbp_learn_result *out) {
-    if (!d || !out) return SBMBP_ERR_ARG;
+    if (!d || !out) return arg_error(__func__, __LINE__);
     device_guard guard(d->device);
     if (!d->have_params || !d->have_state) { set_error("set_params and an initial state must precede learning"); return SBMBP_ERR_STATE; }
     const u32 Q = d->Q, N = d->plan.n_global;
@@ -1394,7 +1395,7 @@ int sbmbp_dist_learning(sbmbp_dist_t *d, float learning_conv_crit, uint32_t lear
 }
 
 int sbmbp_dist_get_stats(sbmbp_dist_t *d, sbmbp_stats *out) {
-    if (!d || !out) return SBMBP_ERR_ARG;
+    if (!d || !out) return arg_error(__func__, __LINE__);
     device_guard guard(d->device);
     CHK(sbmbp_get_stats(d->eng, out));
     out->sweeps = d->total_sweeps;
@@ -1404,7 +1405,7 @@ int sbmbp_dist_get_stats(sbmbp_dist_t *d, sbmbp_stats *out) {
 }
 
 int sbmbp_dist_reset_stats(sbmbp_dist_t *d) {
-    if (!d) return SBMBP_ERR_ARG;
+    if (!d) return arg_error(__func__, __LINE__);
     d->total_sweeps = d->psi_sweeps = 0;
     d->phase_ms[0] = d->phase_ms[1] = d->phase_ms[2] = 0.0;
     d->phase_n = 0;
@@ -1412,13 +1413,13 @@ int sbmbp_dist_reset_stats(sbmbp_dist_t *d) {
 }
 
 int sbmbp_dist_set_timing(sbmbp_dist_t *d, int on) {
-    if (!d) return SBMBP_ERR_ARG;
+    if (!d) return arg_error(__func__, __LINE__);
     d->timing = on != 0;
     return sbmbp_set_timing(d->eng, on);
 }
 
 int sbmbp_dist_phase_times(sbmbp_dist_t *d, double ms_per_sweep[3], uint64_t *n_sweeps) {
-    if (!d || !ms_per_sweep) return SBMBP_ERR_ARG;
+    if (!d || !ms_per_sweep) return arg_error(__func__, __LINE__);
     const double n = d->phase_n ? double(d->phase_n) : 1.0;
     for (int i = 0; i < 3; ++i) ms_per_sweep[i] = d->phase_ms[i] / n;
     if (n_sweeps) *n_sweeps = d->phase_n;
@@ -1428,7 +1429,7 @@ int sbmbp_dist_phase_times(sbmbp_dist_t *d, double ms_per_sweep[3], uint64_t *n_
 // plan of rank `rank` of `world` without a device (tests, dry runs): counts only
 int sbmbp_plan_summary(const sbmbp_graph_t *g, int world, int rank, uint32_t n_chunks, sbmbp_dist_info_t *info, uint64_t *send_rows,
                        uint64_t *recv_rows, uint64_t *msg_rows) {
-    if (!g || !info) return SBMBP_ERR_ARG;
+    if (!g || !info) return arg_error(__func__, __LINE__);
     shard_plan P;
     CHK(build_plan(*g, world, rank, n_chunks ? n_chunks : 1, P));
     info->rank = rank;
@@ -1456,7 +1457,7 @@ int sbmbp_plan_summary(const sbmbp_graph_t *g, int world, int rank, uint32_t n_c
 int sbmbp_plan_arrays(const sbmbp_graph_t *g, int world, int rank, uint32_t n_chunks, uint32_t *nbr_local, uint32_t *halo_global,
                       uint32_t *chunk_row, uint64_t *send_counts_cp, uint64_t *recv_counts_cp, uint32_t *send_idx_chunked,
                       uint32_t *snd_ptr, uint32_t *snd_slot, uint32_t *rev_local, uint32_t *msg_send_edge) {
-    if (!g) return SBMBP_ERR_ARG;
+    if (!g) return arg_error(__func__, __LINE__);
     shard_plan P;
     CHK(build_plan(*g, world, rank, n_chunks ? n_chunks : 1, P));
     auto cp = [](auto &v, auto *dst) { if (dst) std::copy(v.begin(), v.end(), dst); };

@@ -1072,7 +1072,7 @@ int sbmbp_device_count(void) {
 }
 
 int sbmbp_graph_load_edgelist(sbmbp_graph_t **out, const char *path, uint32_t n_vertices) {
-    if (!out || !path) return SBMBP_ERR_ARG;
+    if (!out || !path) return arg_error(__func__, __LINE__);
     std::vector<uint32_t> pairs;
     CHK(read_edgelist(path, pairs));
     auto *g = new sbmbp_graph();
@@ -1082,7 +1082,7 @@ int sbmbp_graph_load_edgelist(sbmbp_graph_t **out, const char *path, uint32_t n_
     return SBMBP_OK;
 }
 int sbmbp_graph_from_edges(sbmbp_graph_t **out, const uint32_t *pairs, uint64_t n_pairs, uint32_t n_vertices) {
-    if (!out || (!pairs && n_pairs)) return SBMBP_ERR_ARG;
+    if (!out || (!pairs && n_pairs)) return arg_error(__func__, __LINE__);
     auto *g = new sbmbp_graph();
     int r = graph_from_pairs(*g, pairs, n_pairs, n_vertices);
     if (r != SBMBP_OK) { delete g; return r; }
@@ -1091,7 +1091,7 @@ int sbmbp_graph_from_edges(sbmbp_graph_t **out, const uint32_t *pairs, uint64_t 
 }
 int sbmbp_graph_from_csr(sbmbp_graph_t **out, uint32_t n, uint64_t e2, const uint64_t *row_ptr, const uint32_t *nbr,
                          const uint32_t *rev) {
-    if (!out) return SBMBP_ERR_ARG;
+    if (!out) return arg_error(__func__, __LINE__);
     auto *g = new sbmbp_graph();
     int r = graph_from_csr(*g, n, e2, row_ptr, nbr, rev);
     if (r != SBMBP_OK) { delete g; return r; }
@@ -1102,7 +1102,7 @@ uint32_t sbmbp_graph_num_vertices(const sbmbp_graph_t *g) { return g ? g->n : 0;
 uint64_t sbmbp_graph_num_directed_edges(const sbmbp_graph_t *g) { return g ? g->e2() : 0; }
 uint32_t sbmbp_graph_max_degree(const sbmbp_graph_t *g) { return g ? g->max_degree : 0; }
 int sbmbp_graph_copy_csr(const sbmbp_graph_t *g, uint64_t *row_ptr, uint32_t *nbr, uint32_t *rev) {
-    if (!g) return SBMBP_ERR_ARG;
+    if (!g) return arg_error(__func__, __LINE__);
     if (row_ptr) std::copy(g->row_ptr.begin(), g->row_ptr.end(), row_ptr);
     if (nbr) std::copy(g->nbr.begin(), g->nbr.end(), nbr);
     if (rev) std::copy(g->rev.begin(), g->rev.end(), rev);
@@ -1111,18 +1111,18 @@ int sbmbp_graph_copy_csr(const sbmbp_graph_t *g, uint64_t *row_ptr, uint32_t *nb
 void sbmbp_graph_destroy(sbmbp_graph_t *g) { delete g; }
 
 int sbmbp_param_from_epsilon_c(uint32_t N, uint32_t Q, double epsilon, double c, double *cab, uint32_t *na) {
-    if (!cab || !na || Q < 1) return SBMBP_ERR_ARG;
+    if (!cab || !na || Q < 1) return arg_error(__func__, __LINE__);
     param_from_epsilon_c(N, Q, epsilon, c, cab, na);
     return SBMBP_OK;
 }
 int sbmbp_param_from_direct(uint32_t N, uint32_t Q, const double *pa, const double *cab_upper, double *cab, uint32_t *na) {
-    if (!cab || !na || !pa || !cab_upper || Q < 1) return SBMBP_ERR_ARG;
+    if (!cab || !na || !pa || !cab_upper || Q < 1) return arg_error(__func__, __LINE__);
     param_from_direct(N, Q, pa, cab_upper, cab, na);
     return SBMBP_OK;
 }
 
 int sbmbp_create(sbmbp_engine_t **out, const sbmbp_graph_t *g, uint32_t Q, uint32_t dc, int device) {
-    if (!out || !g) return SBMBP_ERR_ARG;
+    if (!out || !g) return arg_error(__func__, __LINE__);
     if (Q < 2 || Q > SBMBP_MAX_Q) { set_error("Q must be in [2, 64]"); return SBMBP_ERR_UNSUPPORTED; }
     if (dc > 2) { set_error("deg_corr_flag must be 0, 1 or 2"); return SBMBP_ERR_ARG; }
     if (Q > 16 && dc == 2) { set_error("deg_corr_flag 2 is implemented up to Q = 16"); return SBMBP_ERR_UNSUPPORTED; }
@@ -1255,7 +1255,7 @@ void sbmbp_destroy(sbmbp_engine_t *e) {
 
 int sbmbp_set_stream(sbmbp_engine_t *e, void *hip_stream) {
     device_scope dev_(e);
-    if (!e) return SBMBP_ERR_ARG;
+    if (!e) return arg_error(__func__, __LINE__);
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->own_stream && e->stream) HIPCHK(hipStreamDestroy(e->stream));
     e->stream = static_cast<hipStream_t>(hip_stream);  // 0 is the (legacy) default stream, e.g. torch's current stream
@@ -1287,7 +1287,7 @@ static int upload_labels(sbmbp_engine_t *e, const int32_t *conf, const uint32_t 
 int sbmbp_init_messages(sbmbp_engine_t *e, uint32_t flag, const int32_t *conf, const uint32_t *true_conf, uint32_t seed,
                         int conditional) {
     device_scope dev_(e);
-    if (!e) return SBMBP_ERR_ARG;
+    if (!e) return arg_error(__func__, __LINE__);
     if (flag >= 4) { set_error("bp_messages_init_flag must be < 4"); return SBMBP_ERR_ARG; }  // assert at bp.cpp:106
     if (flag != 0 && !conf) { set_error("init flag != 0 needs a conf vector"); return SBMBP_ERR_ARG; }
     CHK(upload_labels(e, conf, true_conf, flag, conditional));
@@ -1352,7 +1352,7 @@ int sbmbp_init_messages(sbmbp_engine_t *e, uint32_t flag, const int32_t *conf, c
 
 int sbmbp_host_init_state(const sbmbp_graph_t *g, uint32_t Q, uint32_t flag, const int32_t *conf, uint32_t seed, double *psi,
                           double *msg_out) {
-    if (!g || !psi || (!msg_out && !g->nbr.empty()) || Q < 1 || Q > SBMBP_MAX_Q) return SBMBP_ERR_ARG;
+    if (!g || !psi || (!msg_out && !g->nbr.empty()) || Q < 1 || Q > SBMBP_MAX_Q) return arg_error(__func__, __LINE__);
     if (flag >= 4) { set_error("bp_messages_init_flag must be < 4"); return SBMBP_ERR_ARG; }
     if (flag != 0 && !conf) { set_error("init flag != 0 needs a conf vector"); return SBMBP_ERR_ARG; }
     std::vector<uint32_t> rp32(g->row_ptr.begin(), g->row_ptr.end());
@@ -1362,7 +1362,7 @@ int sbmbp_host_init_state(const sbmbp_graph_t *g, uint32_t Q, uint32_t flag, con
 
 int sbmbp_init_messages_device(sbmbp_engine_t *e, uint64_t seed, const uint32_t *true_conf) {
     device_scope dev_(e);
-    if (!e) return SBMBP_ERR_ARG;
+    if (!e) return arg_error(__func__, __LINE__);
     CHK(upload_labels(e, nullptr, true_conf, 0, 0));
     // random marginals (counter-based generator keyed by the GLOBAL row id, so shards draw what the single engine draws);
     // every out-message of a row starts as the row's marginal
@@ -1386,7 +1386,7 @@ int sbmbp_init_messages_device(sbmbp_engine_t *e, uint64_t seed, const uint32_t 
 
 int sbmbp_set_params(sbmbp_engine_t *e, const double *cab, const uint32_t *na, double beta) {
     device_scope dev_(e);
-    if (!e || !cab || !na) return SBMBP_ERR_ARG;
+    if (!e || !cab || !na) return arg_error(__func__, __LINE__);
     apply_params_host(e, cab, na, beta);
     if (e->wide && !e->w_positive) { set_error("above Q = 16 every cab entry must be > 0"); e->have_params = false; return SBMBP_ERR_UNSUPPORTED; }
     return upload_params(e, 0.0);
@@ -1452,7 +1452,7 @@ static int download_messages(sbmbp_engine *e, const double *src, double *msg_out
 
 int sbmbp_set_state(sbmbp_engine_t *e, const double *psi, const double *msg_out) {
     device_scope dev_(e);
-    if (!e) return SBMBP_ERR_ARG;
+    if (!e) return arg_error(__func__, __LINE__);
     if (psi) HIPCHK(hipMemcpyAsync(e->d_psi[e->pcur], psi, size_t(e->N) * e->Q * 8, hipMemcpyHostToDevice, e->stream));
     if (msg_out && e->E2) CHK(upload_messages(e, msg_out, e->d_M[e->cur]));
     // a sharded engine takes the declared state as (psi^0, m^-1): sweep 0 reads the buffer it then overwrites
@@ -1468,7 +1468,7 @@ int sbmbp_set_state(sbmbp_engine_t *e, const double *psi, const double *msg_out)
 }
 int sbmbp_get_state(sbmbp_engine_t *e, double *psi, double *msg_out) {
     device_scope dev_(e);
-    if (!e) return SBMBP_ERR_ARG;
+    if (!e) return arg_error(__func__, __LINE__);
     if (psi) HIPCHK(hipMemcpyAsync(psi, e->d_psi[e->pcur], size_t(e->N) * e->Q * 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (msg_out && e->E2) CHK(download_messages(e, e->d_M[e->cur], msg_out));
@@ -1476,7 +1476,7 @@ int sbmbp_get_state(sbmbp_engine_t *e, double *psi, double *msg_out) {
 }
 int sbmbp_get_field(sbmbp_engine_t *e, double *h) {
     device_scope dev_(e);
-    if (!e || !h) return SBMBP_ERR_ARG;
+    if (!e || !h) return arg_error(__func__, __LINE__);
     NOT_SHARD(e);
     CHK(refresh_field(e));
     if (e->wide) {
@@ -1495,7 +1495,7 @@ int sbmbp_get_field(sbmbp_engine_t *e, double *h) {
 
 int sbmbp_set_schedule(sbmbp_engine_t *e, double field_mix, uint32_t check_every) {
     device_scope dev_(e);
-    if (!e || !(field_mix > 0.0) || field_mix > 1.0 || check_every < 1) return SBMBP_ERR_ARG;
+    if (!e || !(field_mix > 0.0) || field_mix > 1.0 || check_every < 1) return arg_error(__func__, __LINE__);
     e->field_mix = field_mix;
     e->check_every = check_every;
     return SBMBP_OK;
@@ -1503,19 +1503,19 @@ int sbmbp_set_schedule(sbmbp_engine_t *e, double field_mix, uint32_t check_every
 
 int sbmbp_set_learning_schedule(sbmbp_engine_t *e, double field_mix, double snap) {
     device_scope dev_(e);
-    if (!e || !(field_mix > 0.0) || field_mix > 1.0 || !(snap >= 0.0)) return SBMBP_ERR_ARG;
+    if (!e || !(field_mix > 0.0) || field_mix > 1.0 || !(snap >= 0.0)) return arg_error(__func__, __LINE__);
     e->learn_field_mix = field_mix;
     e->learn_snap = snap;
     return SBMBP_OK;
 }
 
 int sbmbp_set_auto_relax(sbmbp_engine_t *e, int on) {
-    if (!e) return SBMBP_ERR_ARG;
+    if (!e) return arg_error(__func__, __LINE__);
     e->auto_relax = on != 0;
     return SBMBP_OK;
 }
 int sbmbp_get_relaxation(const sbmbp_engine_t *e, int *field_level, int *generic_level, double *field_mix, double *damping_factor) {
-    if (!e) return SBMBP_ERR_ARG;
+    if (!e) return arg_error(__func__, __LINE__);
     if (field_level) *field_level = e->ar_fl;
     if (generic_level) *generic_level = e->ar_gl;
     if (field_mix) *field_mix = std::min(std::min(e->field_mix, ar_field_cap(e->ar_fl)), ar_gen_mix(e->ar_gl));
@@ -1525,20 +1525,20 @@ int sbmbp_get_relaxation(const sbmbp_engine_t *e, int *field_level, int *generic
 
 int sbmbp_set_gather_mode(sbmbp_engine_t *e, int mode) {
     device_scope dev_(e);
-    if (!e || mode < 0 || mode > 1) return SBMBP_ERR_ARG;
+    if (!e || mode < 0 || mode > 1) return arg_error(__func__, __LINE__);
     e->gather_mode = mode;
     return SBMBP_OK;
 }
 
 int sbmbp_converge(sbmbp_engine_t *e, double crit, uint32_t max_sweeps, double damping, int *niter, double *last) {
     device_scope dev_(e);
-    if (!e) return SBMBP_ERR_ARG;
+    if (!e) return arg_error(__func__, __LINE__);
     NOT_SHARD(e);
     return run_sweeps(e, crit, max_sweeps, damping, niter, last);
 }
 int sbmbp_sweep(sbmbp_engine_t *e, double damping, uint32_t n_sweeps, double *last) {
     device_scope dev_(e);
-    if (!e) return SBMBP_ERR_ARG;
+    if (!e) return arg_error(__func__, __LINE__);
     NOT_SHARD(e);
     const uint32_t keep = e->check_every;
     e->check_every = std::max<uint32_t>(keep, 64);  // no convergence test: sync rarely
@@ -1549,45 +1549,45 @@ int sbmbp_sweep(sbmbp_engine_t *e, double damping, uint32_t n_sweeps, double *la
 
 int sbmbp_free_energy(sbmbp_engine_t *e, double *f, double *parts) {
     device_scope dev_(e);
-    if (!e) return SBMBP_ERR_ARG;
+    if (!e) return arg_error(__func__, __LINE__);
     NOT_SHARD(e);
     return free_energy_impl(e, f, parts);
 }
 int sbmbp_entropy(sbmbp_engine_t *e, double *ent, double *parts) {
     device_scope dev_(e);
-    if (!e) return SBMBP_ERR_ARG;
+    if (!e) return arg_error(__func__, __LINE__);
     NOT_SHARD(e);
     return entropy_impl(e, ent, parts);
 }
 int sbmbp_set_nonedge_mode(sbmbp_engine_t *e, int mode, int order) {
     device_scope dev_(e);
-    if (!e || mode < 0 || mode > 2 || order < 0 || order > 4) return SBMBP_ERR_ARG;
+    if (!e || mode < 0 || mode > 2 || order < 0 || order > 4) return arg_error(__func__, __LINE__);
     e->nonedge_mode = mode;
     e->series_order = order;
     return SBMBP_OK;
 }
 int sbmbp_em_expectations(sbmbp_engine_t *e, double *na_e, double *nna_e, double *cab_e) {
     device_scope dev_(e);
-    if (!e) return SBMBP_ERR_ARG;
+    if (!e) return arg_error(__func__, __LINE__);
     NOT_SHARD(e);
     return em_expect(e, na_e, nna_e, cab_e);
 }
 int sbmbp_confusion(sbmbp_engine_t *e, double *C) {
     device_scope dev_(e);
-    if (!e || !C) return SBMBP_ERR_ARG;
+    if (!e || !C) return arg_error(__func__, __LINE__);
     NOT_SHARD(e);
     return overlap_impl(e, nullptr, C);
 }
 int sbmbp_overlap(sbmbp_engine_t *e, double *ov) {
     device_scope dev_(e);
-    if (!e || !ov) return SBMBP_ERR_ARG;
+    if (!e || !ov) return arg_error(__func__, __LINE__);
     NOT_SHARD(e);
     return overlap_impl(e, ov, nullptr);
 }
 
 int sbmbp_inference(sbmbp_engine_t *e, float conv_crit, uint32_t time_conv, float dumping_rate, sbmbp_infer_result *out) {
     device_scope dev_(e);
-    if (!e || !out) return SBMBP_ERR_ARG;
+    if (!e || !out) return arg_error(__func__, __LINE__);
     NOT_SHARD(e);
     // belief_propagation::inference (bp.cpp:77-99); crit and damping arrive as float, compared as double (:406)
     CHK(run_sweeps(e, double(conv_crit), time_conv, double(dumping_rate), &out->niter, &out->last_maxdiff));
@@ -1610,7 +1610,7 @@ int sbmbp_inference(sbmbp_engine_t *e, float conv_crit, uint32_t time_conv, floa
 int sbmbp_learning(sbmbp_engine_t *e, float learning_conv_crit, uint32_t learning_max_time, float learning_rate,
                    float dumping_rate, sbmbp_learn_result *out) {
     device_scope dev_(e);
-    if (!e || !out) return SBMBP_ERR_ARG;
+    if (!e || !out) return arg_error(__func__, __LINE__);
     NOT_SHARD(e);
     if (!e->have_params || !e->have_state) { set_error("set_params and init_messages must precede learning"); return SBMBP_ERR_STATE; }
     const uint32_t Q = e->Q;
@@ -1667,7 +1667,7 @@ int sbmbp_learning(sbmbp_engine_t *e, float learning_conv_crit, uint32_t learnin
 
 int sbmbp_get_stats(sbmbp_engine_t *e, sbmbp_stats *out) {
     device_scope dev_(e);
-    if (!e || !out) return SBMBP_ERR_ARG;
+    if (!e || !out) return arg_error(__func__, __LINE__);
     out->sweeps = e->sweeps;
     out->edge_msg_updates = e->sweeps * e->E2;
     out->sweep_kernel_ms = e->sweep_ms;
@@ -1683,7 +1683,7 @@ int sbmbp_get_stats(sbmbp_engine_t *e, sbmbp_stats *out) {
 }
 int sbmbp_reset_stats(sbmbp_engine_t *e) {
     device_scope dev_(e);
-    if (!e) return SBMBP_ERR_ARG;
+    if (!e) return arg_error(__func__, __LINE__);
     e->sweeps = 0;
     e->psi_sweeps = 0;
     e->sweep_ms = 0.0;
@@ -1692,7 +1692,7 @@ int sbmbp_reset_stats(sbmbp_engine_t *e) {
 }
 int sbmbp_set_timing(sbmbp_engine_t *e, int on) {
     device_scope dev_(e);
-    if (!e) return SBMBP_ERR_ARG;
+    if (!e) return arg_error(__func__, __LINE__);
     e->timing = on != 0;
     return SBMBP_OK;
 }
@@ -1700,7 +1700,7 @@ int sbmbp_set_timing(sbmbp_engine_t *e, int on) {
 // ------------------------------------------ shard steps ------------------------------------------
 
 int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *d, uint32_t Q, uint32_t dc, int device) {
-    if (!out || !d || !d->row_ptr || (!d->nbr_local && d->n_edges) || !d->psi_buf0 || !d->psi_buf1 || !d->red_buf) return SBMBP_ERR_ARG;
+    if (!out || !d || !d->row_ptr || (!d->nbr_local && d->n_edges) || !d->psi_buf0 || !d->psi_buf1 || !d->red_buf) { set_error("sbmbp_shard_create: null argument"); return SBMBP_ERR_ARG; }
     if (Q < 2 || Q > 16) { set_error("sharded engines: Q must be in [2, 16]"); return SBMBP_ERR_UNSUPPORTED; }
     if (dc > 2) { set_error("deg_corr_flag must be 0, 1 or 2"); return SBMBP_ERR_ARG; }
     if (dc == 2 && (!d->rev_local || !d->table_deg)) { set_error("a dc 2 shard needs rev_local and table_deg (it runs the message-gather sweep)"); return SBMBP_ERR_ARG; }
@@ -1754,7 +1754,12 @@ int sbmbp_shard_create(sbmbp_engine_t **out, const sbmbp_shard_desc *d, uint32_t
             e->chunk_hub.push_back(uint32_t(hub_row.size()));
             ++next_chunk;
         }
-        if (d->row_ptr[i + 1] < d->row_ptr[i]) { delete e; set_error("row_ptr not monotone"); return SBMBP_ERR_ARG; }
+        if (d->row_ptr[i + 1] < d->row_ptr[i]) {
+            set_error("shard row_ptr not monotone at local row " + std::to_string(i) + " of " + std::to_string(d->n_own) + ": " +
+                      std::to_string(d->row_ptr[i]) + " then " + std::to_string(d->row_ptr[i + 1]) + " (n_edges " + std::to_string(d->n_edges) + ")");
+            delete e;
+            return SBMBP_ERR_ARG;
+        }
         const uint32_t dg = uint32_t(d->row_ptr[i + 1] - d->row_ptr[i]);
         if (dg > cap) {
             if (rows) { blk_row.push_back(i); rows = 0; edges = 0; }
@@ -1852,7 +1857,7 @@ int sbmbp_shard_set_labels(sbmbp_engine_t *e, const int32_t *conf, const uint32_
 
 int sbmbp_shard_query(sbmbp_engine_t *e, int what) {
     device_scope dev_(e);
-    if (!e) return SBMBP_ERR_ARG;
+    if (!e) return arg_error(__func__, __LINE__);
     switch (what) {
         case 0: return e->w_positive ? 1 : 0;
         case 1: return e->has_clamp ? 1 : 0;
@@ -1866,7 +1871,7 @@ int sbmbp_shard_query(sbmbp_engine_t *e, int what) {
 int sbmbp_shard_set_incoming(sbmbp_engine_t *e, int source) {
     device_scope dev_(e);
     IS_SHARD(e);
-    if (source != 0 && !(source == 1 && e->d_rev)) return SBMBP_ERR_ARG;
+    if (source != 0 && !(source == 1 && e->d_rev)) return arg_error(__func__, __LINE__);
     e->incoming_src = source;
     return SBMBP_OK;
 }
@@ -1932,7 +1937,7 @@ int sbmbp_shard_sweep_explicit(sbmbp_engine_t *e, uint32_t j, double damping) {
 int sbmbp_shard_state_record(sbmbp_engine_t *e, int slot) {
     device_scope dev_(e);
     IS_SHARD(e);
-    if (slot < 0 || slot > 1) return SBMBP_ERR_ARG;
+    if (slot < 0 || slot > 1) return arg_error(__func__, __LINE__);
     if (!e->h_cs) {
         HIPCHK(hipHostMalloc(&e->h_cs, 2 * sizeof(conv_state), hipHostMallocDefault));
         for (auto &ev : e->ev_cs) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1946,7 +1951,7 @@ int sbmbp_shard_state_record(sbmbp_engine_t *e, int slot) {
 int sbmbp_shard_state_wait(sbmbp_engine_t *e, int slot, sbmbp_conv_state *out) {
     device_scope dev_(e);
     IS_SHARD(e);
-    if (slot < 0 || slot > 1 || !out || !e->h_cs) return SBMBP_ERR_ARG;
+    if (slot < 0 || slot > 1 || !out || !e->h_cs) return arg_error(__func__, __LINE__);
     HIPCHK(hipEventSynchronize(e->ev_cs[slot]));
     const conv_state &cs = static_cast<conv_state *>(e->h_cs)[slot];
     out->maxdiff = cs.maxdiff;
@@ -1984,9 +1989,9 @@ int sbmbp_shard_set_io(sbmbp_engine_t *e, const uint32_t *snd_ptr, const uint32_
                        const double *d_stage0, const double *d_stage1, uint32_t ncomp) {
     device_scope dev_(e);
     IS_SHARD(e);
-    if (!snd_ptr || (ncomp != e->Q && ncomp + 1 != e->Q)) return SBMBP_ERR_ARG;
+    if (!snd_ptr || (ncomp != e->Q && ncomp + 1 != e->Q)) return arg_error(__func__, __LINE__);
     const uint32_t n_slots = snd_ptr[e->N];
-    if ((n_slots && (!snd_slot || !d_sendbuf)) || (e->n_halo && (!d_stage0 || !d_stage1))) return SBMBP_ERR_ARG;
+    if ((n_slots && (!snd_slot || !d_sendbuf)) || (e->n_halo && (!d_stage0 || !d_stage1))) return arg_error(__func__, __LINE__);
     if (e->d_snd_ptr) { hipFree(e->d_snd_ptr); e->d_snd_ptr = nullptr; }
     if (e->d_snd_slot) { hipFree(e->d_snd_slot); e->d_snd_slot = nullptr; }
     CHK(dev_alloc(e, &e->d_snd_ptr, size_t(e->N) + 1));
@@ -2004,7 +2009,7 @@ int sbmbp_shard_set_io(sbmbp_engine_t *e, const uint32_t *snd_ptr, const uint32_
 int sbmbp_shard_pack(sbmbp_engine_t *e, uint32_t j, const uint32_t *d_idx, uint32_t n, double *d_out, uint32_t ncomp) {
     device_scope dev_(e);
     IS_SHARD(e);
-    if (ncomp != e->Q && ncomp + 1 != e->Q) return SBMBP_ERR_ARG;
+    if (ncomp != e->Q && ncomp + 1 != e->Q) return arg_error(__func__, __LINE__);
     if (n == 0) return SBMBP_OK;
     const double *table = e->d_psi[(e->pcur + int(j)) & 1];
     const uint64_t tot = uint64_t(n) * ncomp;
@@ -2017,7 +2022,7 @@ int sbmbp_shard_pack(sbmbp_engine_t *e, uint32_t j, const uint32_t *d_idx, uint3
 int sbmbp_shard_unpack(sbmbp_engine_t *e, uint32_t j, const double *d_in, const uint32_t *d_halo_row, uint32_t n, uint32_t ncomp) {
     device_scope dev_(e);
     IS_SHARD(e);
-    if ((ncomp != e->Q && ncomp + 1 != e->Q) || n > e->n_halo || (n && !d_halo_row)) return SBMBP_ERR_ARG;
+    if ((ncomp != e->Q && ncomp + 1 != e->Q) || n > e->n_halo || (n && !d_halo_row)) return arg_error(__func__, __LINE__);
     if (n == 0) return SBMBP_OK;
     double *table = e->d_psi[(e->pcur + int(j)) & 1];
     hipLaunchKernelGGL(k_unpack_rows, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, d_in, n, int(e->Q), int(ncomp), table,
@@ -2119,7 +2124,7 @@ int sbmbp_shard_sweep_partial(sbmbp_engine_t *e, uint32_t j) {
 int sbmbp_shard_finalize(sbmbp_engine_t *e, int mode, uint32_t n_rows, int md_exact) {
     device_scope dev_(e);
     IS_SHARD(e);
-    if ((mode != 0 && mode != 1) || n_rows == 0 || n_rows > 64u * SBMBP_FOLD_ROWS) return SBMBP_ERR_ARG;
+    if ((mode != 0 && mode != 1) || n_rows == 0 || n_rows > 64u * SBMBP_FOLD_ROWS) return arg_error(__func__, __LINE__);
     DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_finalize<QQ>), dim3(1), dim3(BLOCK), 0, e->stream, e->d_red + SBMBP_RED_GATHER_OFFSET, n_rows, mode, e->d_P, e->d_hist, e->hist_cap, md_exact));
     HIPCHK(hipGetLastError());
     return SBMBP_OK;
@@ -2155,7 +2160,7 @@ int sbmbp_shard_rowsums_partial(sbmbp_engine_t *e) {
 int sbmbp_shard_poll(sbmbp_engine_t *e, sbmbp_conv_state *out) {
     device_scope dev_(e);
     IS_SHARD(e);
-    if (!out) return SBMBP_ERR_ARG;
+    if (!out) return arg_error(__func__, __LINE__);
     conv_state cs;
     CHK(read_conv_state(e, &cs));
     if (e->timing) CHK(collect_timing(e));
@@ -2254,7 +2259,7 @@ int sbmbp_shard_fe_finish(sbmbp_engine_t *e, double *out) {
 int sbmbp_shard_nonedge_partial(sbmbp_engine_t *e, int want_entropy, uint32_t *n_values, int *order) {
     device_scope dev_(e);
     IS_SHARD(e);
-    if (!n_values || !order) return SBMBP_ERR_ARG;
+    if (!n_values || !order) return arg_error(__func__, __LINE__);
     const uint32_t Q = e->Q;
     if (e->dc != 0) { *n_values = 0; *order = 0; return SBMBP_OK; }
     std::vector<double> mats;
@@ -2291,7 +2296,7 @@ int sbmbp_shard_nonedge_partial(sbmbp_engine_t *e, int want_entropy, uint32_t *n
 int sbmbp_shard_nonedge_exact_partial(sbmbp_engine_t *e, const double *d_psi_all, int want_entropy) {
     device_scope dev_(e);
     IS_SHARD(e);
-    if (!d_psi_all) return SBMBP_ERR_ARG;
+    if (!d_psi_all) return arg_error(__func__, __LINE__);
     const uint32_t Q = e->Q;
     if (e->dc != 0) { HIPCHK(hipMemsetAsync(e->d_red, 0, 4 * 8, e->stream)); return SBMBP_OK; }
     std::vector<double> mats;
@@ -2358,7 +2363,7 @@ int sbmbp_shard_nonedge_finish(sbmbp_engine_t *e, int want_entropy, int order, d
 int sbmbp_shard_em_partial(sbmbp_engine_t *e, uint32_t *n_values) {
     device_scope dev_(e);
     IS_SHARD(e);
-    if (!n_values) return SBMBP_ERR_ARG;
+    if (!n_values) return arg_error(__func__, __LINE__);
     const uint32_t Q = e->Q, R = 2 * Q + Q * Q, T = Q * (Q + 1) / 2;
     CHK(shard_materialize(e));
     CHK(sbmbp_shard_rowsums_partial(e));

@@ -27,6 +27,10 @@ namespace sbmbp {
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 const std::string &get_error() { return g_err; }
+int arg_error(const char *func, int line) {
+    g_err = std::string("invalid argument (") + func + ", check at line " + std::to_string(line) + ")";
+    return -1;  // SBMBP_ERR_ARG
+}
 
 // run fn(t, lo, hi) over [0, n) split into contiguous pieces on up to `want` threads
 template <typename F> static void parallel_ranges(uint64_t n, unsigned want, F fn) {

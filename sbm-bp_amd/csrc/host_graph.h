@@ -21,6 +21,7 @@ namespace sbmbp {
 
 void set_error(const std::string &msg);
 const std::string &get_error();
+int arg_error(const char *func, int line);  // SBMBP_ERR_ARG with a message that names the check (never a stale one)
 
 // returns 0 or an SBMBP_ERR_* code
 int graph_from_pairs(sbmbp_graph &g, const uint32_t *pairs, uint64_t n_pairs, uint32_t n_vertices);
