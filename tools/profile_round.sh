@@ -10,9 +10,14 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python3 -c "from bench import source_sha; print(source_sha())" > $OUT/source_sha.txt  # the sources everything below is measured on
 # counters first: the benches below then find a PMC summary collected on THESE sources and report roofline.traffic from it
-for WL in C3 C4 C2; do
-  tools/pmc_workload.sh $R $WL > $OUT/pmc_$WL.log 2>&1 || echo "pmc $WL failed" >&2
-done
+# (a gpurun call is limited to 20 minutes: PROFILE_PART=pmc runs the counter passes only, PROFILE_PART=rest everything else)
+PART=${PROFILE_PART:-all}
+if [ $PART != rest ]; then
+  for WL in C3 C4 C2 Q64; do
+    tools/pmc_workload.sh $R $WL > $OUT/pmc_$WL.log 2>&1 || echo "pmc $WL failed" >&2
+  done
+fi
+[ $PART = pmc ] && { echo "profile round $R: counters done" >&2; exit 0; }
 for WL in C3 C2 C4 C5; do
   echo "== bench $WL" >&2
   if [ $WL = C3 ]; then python3 bench.py --workload $WL --converge > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err || exit 1
@@ -26,7 +31,6 @@ for WL in Q32 Q48 Q64; do
   python3 bench.py --workload $WL --no-cpu-baseline --converge > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err || echo "bench $WL failed" >&2
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_Q32 -o run -- python3 bench.py --workload Q32 --no-cpu-baseline --no-converge > $OUT/stats_Q32.log 2>&1 || echo "stats Q32 failed" >&2
-tools/pmc_workload.sh $R Q64 > $OUT/pmc_Q64.log 2>&1 || echo "pmc Q64 failed" >&2
 echo "== bench C3, 200 timed steps" >&2
 python3 bench.py --workload C3 --steps 200 --warmup 5 --no-cpu-baseline --no-converge > $OUT/bench_C3_200steps.json 2> $OUT/bench_C3_200steps.err || exit 1
 echo "== bench C3 --gather messages" >&2
