@@ -48,6 +48,8 @@ WORKLOADS = {
     # power-law degrees cost
     "Q8": (1_000_000, 8, 8.0, 0.1, 0, 3),
     "Q8dc": (1_000_000, 8, 8.0, 0.1, 1, 3),
+    "Q12": (1_000_000, 12, 8.0, 0.1, 0, 8),
+    "Q16": (1_000_000, 16, 8.0, 0.1, 0, 9),
     # label counts above 16: the matrix-core kernels (csrc/kernels_wide.h; message-gather form, full Q-component records)
     "Q32": (1_000_000, 32, 8.0, 0.1, 0, 5),
     "Q48": (500_000, 48, 8.0, 0.1, 0, 7),
@@ -60,7 +62,7 @@ CONV_CRIT = 5e-6       # the reference's default -e (main.cpp:113)
 def source_sha():
     """identifies the kernel sources a number was measured on (the GPU box has no .git): profiles/*.json carry it"""
     h = hashlib.sha256()
-    for f in ("kernels.h", "engine.hip", "dist.hip", "host_graph.cpp"):
+    for f in ("kernels.h", "kernels_wide.h", "engine.hip", "dist.hip", "host_graph.cpp"):
         p = os.path.join(ROOT, "sbm-bp_amd", "csrc", f)
         if os.path.exists(p):
             h.update(open(p, "rb").read())

@@ -585,8 +585,9 @@ __device__ __forceinline__ void edge_field(const dev_params *__restrict__ P, con
 // K1: one synchronous sweep over the rows of this workgroup's segment.
 // partials[b*(Q+1) + q] = sum_rows g_i psi_i[q],  partials[b*(Q+1)+Q] = max |delta message|.
 // ------------------------------------------------------------------------------------------------
+template <int Q> struct sweep_waves { static constexpr int N = Q == 16 ? 2 : 1; };  // register target, see k_sweep_psi (Q = 16: 258 - 265 registers otherwise)
 template <int Q, bool DC2>
-__global__ void __launch_bounds__(frame_cfg<Q>::TPB)
+__global__ void __launch_bounds__(frame_cfg<Q>::TPB) __attribute__((amdgpu_waves_per_eu(sweep_waves<Q>::N)))
 k_sweep(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr, const uint32_t *__restrict__ ndeg /* degree of every table row (DC2 only) */,
         const double *__restrict__ Mold, double *__restrict__ Mnew, const double *__restrict__ psi_old,
         double *__restrict__ psi, const int32_t *__restrict__ clamp, const uint32_t *__restrict__ blk_row,
@@ -1054,13 +1055,18 @@ struct hub_frags {
 // CLAMP: rows with clamp[i] != -1 (bp_conditional, bp.cpp:1100-1126) keep their marginal and out-messages. Their state is
 // one-hot (-i 1 / -f), and for a one-hot neighbour the reconstruction psi_l / (W^T m) normalises to that same one-hot
 // vector exactly, so clamped rows need no special case on the receiving side.
-template <int Q, bool CLAMP, bool SHARD>
-__global__ void
-#if SBMBP_PSI_WAVES > 0
-__launch_bounds__(frame_cfg<Q>::TPB, SBMBP_PSI_WAVES)
-#else
-__launch_bounds__(frame_cfg<Q>::TPB)
+// Register targets (waves per SIMD the allocation must leave room for; 1 = none). Q = 16 needs 260 registers left alone, which
+// is ONE wave per SIMD; capped at 255 it runs two (Q = 16 control workload: 1.49 -> 0.95 ms, 27 -> 42 % of the roofline; a third
+// wave spills 256 B and loses again: 1.24 ms).
+#ifndef SBMBP_PSI_WAVES_Q16
+#define SBMBP_PSI_WAVES_Q16 2
 #endif
+#ifndef SBMBP_PSI_WAVES_Q9
+#define SBMBP_PSI_WAVES_Q9 1   // Q = 9 .. 12
+#endif
+template <int Q> struct psi_waves { static constexpr int N = SBMBP_PSI_WAVES > 0 ? SBMBP_PSI_WAVES : (Q == 16 ? SBMBP_PSI_WAVES_Q16 : (Q >= 9 && Q <= 12) ? SBMBP_PSI_WAVES_Q9 : 1); };
+template <int Q, bool CLAMP, bool SHARD>
+__global__ void __launch_bounds__(frame_cfg<Q>::TPB) __attribute__((amdgpu_waves_per_eu(psi_waves<Q>::N)))
 k_sweep_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, double *__restrict__ Mio,
             const double *__restrict__ psi_old, double *__restrict__ psi_new, const uint32_t *__restrict__ blk_row,
             const uint32_t *__restrict__ blk_e0, const dev_params *__restrict__ P, int dc, double *__restrict__ partials,

@@ -208,3 +208,55 @@ def test_bench_launcher_passes_a_sigterm_on():
     # no rank process of that launcher is left behind
     out = subprocess.run(["ps", "-eo", "ppid,pid,args"], capture_output=True, text=True).stdout
     assert not [l for l in out.splitlines() if l.split()[0] == str(pr.pid)]
+
+
+def test_shard_plan_under_asan_with_rank_threads(tmp_path):
+    """the plan code of csrc/dist.hip (host code; the ranks of `bin/bp --gpus N` and of LocalShards build their plans side by
+    side as threads over ONE shared graph) compiled with the host side instrumented by AddressSanitizer - device code
+    untouched: GPU AddressSanitizer is not available on this pool - and driven by concurrent rank threads"""
+    import shutil
+    import subprocess
+    import sys
+    from conftest import ROOT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not (os.path.exists(hipcc) and os.path.exists(clang)):
+        pytest.skip("no hipcc")
+    rt = subprocess.run([clang, "--print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(rt) or not os.path.exists(rt):
+        pytest.skip("no shared AddressSanitizer runtime in this toolchain")
+    lib = tmp_path / "libsbmbp_asan.so"
+    csrc = os.path.join(ROOT, "sbm-bp_amd", "csrc")
+    subprocess.run([hipcc, "-std=c++14", "-O1", "-g", "-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan", "--offload-arch=gfx950",
+                    "-fPIC", "-shared", "-pthread", "-DSBMBP_ONLY_Q=4", "-o", str(lib)] +
+                   [os.path.join(csrc, f) for f in ("engine.hip", "dist.hip", "host_graph.cpp")] + ["-lrccl"], check=True, timeout=900)
+    prog = r"""
+import sys, threading
+sys.path[:0] = [%r, %r, %r]
+import numpy as np
+import sbm_bp_amd as S
+from shard_protocol_model import CppPlan
+rng = np.random.default_rng(3)
+N = 3000
+pairs = rng.integers(0, N, size=(12000, 2)).astype(np.uint32)
+pairs = np.concatenate([pairs, np.stack([np.zeros(700, dtype=np.uint32), np.arange(1, 701, dtype=np.uint32)], 1)])  # one long row
+for it in range(6):
+    g = S.Graph.from_edges(pairs, N)
+    for world, nc in ((3, 4), (5, 1), (2, 3), (8, 2)):
+        errs = []
+        def work(r):
+            try:
+                p = CppPlan(g, world, r, nc)
+                assert (np.diff(p.snd_ptr.astype(np.int64)) >= 0).all()
+            except Exception as ex:
+                errs.append((r, repr(ex)))
+        ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errs, errs
+print("plans ok")
+""" % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle"))
+    pr = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=900,
+                        env=dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", SBMBP_LIB=str(lib)))
+    assert pr.returncode == 0 and "plans ok" in pr.stdout, (pr.stdout[-500:], pr.stderr[-3000:])
+    assert "AddressSanitizer" not in pr.stderr
