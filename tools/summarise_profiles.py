@@ -8,7 +8,7 @@ from bench import source_sha
 OUT = os.path.join(ROOT, "gpurun_out", "profile_" + R)
 PROF = os.path.join(ROOT, "profiles")
 os.makedirs(PROF, exist_ok=True)
-for wl in (() if PMC_ONLY else ("C3", "C2", "C4", "C5", "Q32", "Q48", "Q64")):
+for wl in (() if PMC_ONLY else ("C3", "C2", "C4", "C5", "Q12", "Q16", "Q32", "Q48", "Q64")):
     st = glob.glob(os.path.join(OUT, "stats_" + wl, "**", "*kernel_stats.csv"), recursive=True)
     if st:
         shutil.copy(st[0], os.path.join(PROF, "%s_%s_kernel_stats.csv" % (R, wl.lower())))
