@@ -546,6 +546,9 @@ struct ar_t {
         hold = 1 << 30;  // the ladder is used up: the run goes on as it is
     }
     void esc_field() {
+        // a swing of the field sums that shows although the generic ladder has already softened the field is driven by the
+        // messages, not by the field's own feedback: damping answers it, a still softer field only slows everything down
+        if (gl >= 0) { if (gl < 1) gl = 1; esc_gen(); return; }
         int nf = fl;
         while (nf + 1 < NF && !(FIELD[nf] < mix())) ++nf;   // the next cap that actually lowers the mix
         if (FIELD[nf] < mix()) { fl = nf; reset_after(); trace("field"); }

@@ -866,6 +866,9 @@ __device__ __forceinline__ void finalize_update(dev_params *__restrict__ P, cons
             hold = 1 << 30;  // the ladder is used up: the run goes on as it is
         };
         auto esc_field = [&]() {
+            // a swing of the field sums that shows although the generic ladder has already softened the field is driven by the
+            // messages, not by the field's own feedback: damping answers it, a still softer field only slows everything down
+            if (gl >= 0) { if (gl < 1) gl = 1; esc_gen(); return; }
             int nf = fl;
             while (nf + 1 < AR_NF && !(ar_field_cap(nf) < cur_mix())) ++nf;  // the next cap that actually lowers the mix
             if (ar_field_cap(nf) < cur_mix()) { fl = nf; reset_after(); }

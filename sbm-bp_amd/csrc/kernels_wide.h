@@ -439,6 +439,7 @@ k_wfinalize(const double *__restrict__ partials, uint32_t n_part, int mode, dev_
                 hold = 1 << 30;
             };
             auto esc_field = [&]() {
+                if (gl >= 0) { if (gl < 1) gl = 1; esc_gen(); return; }  // (finalize_update: a message-driven swing)
                 int nf = fl;
                 while (nf + 1 < AR_NF && !(ar_field_cap(nf) < cur_mix())) ++nf;
                 if (ar_field_cap(nf) < cur_mix()) { fl = nf; reset_after(); }
