@@ -1371,9 +1371,10 @@ int sbmbp_init_messages_device(sbmbp_engine_t *e, uint64_t seed, const uint32_t 
     if (e->E2 && e->wide)
         hipLaunchKernelGGL(k_winit_msgs_from_psi, dim3(e->N), dim3(BLOCK), 0, e->stream, e->d_row_ptr, e->d_psi[e->pcur], e->N, int(e->Q),
                            e->d_M[0], e->d_M[1]);
-    else if (e->E2)
-        hipLaunchKernelGGL(k_init_msgs_from_psi, dim3((e->N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, e->d_row_ptr,
-                           e->d_psi[e->pcur], e->N, int(e->Q), e->d_M[0], e->d_M[1]);
+    else if (e->E2) {
+        DISPATCH_Q(e->Q, hipLaunchKernelGGL((k_init_msgs_from_psi_seg<QQ>), dim3(e->n_blk), dim3(frame_cfg<QQ>::TPB), 0, e->stream, e->d_row_ptr,
+                                            e->d_psi[e->pcur], e->d_blk_row, e->d_blk_e0, e->d_M[0], e->d_M[1]));
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     e->have_state = true;

@@ -1937,8 +1937,12 @@ template <int Q, bool EM> struct fe_psi_cfg {
     static constexpr int T = EM ? Q * (Q + 1) / 2 : 0;
     static constexpr int NP = FE_NP + NE_NP + T;
 };
+#ifndef SBMBP_FE_WAVES_Q8
+#define SBMBP_FE_WAVES_Q8 2   // k_fe_psi<8>: 356 - 470 registers left alone; at 256 (two waves per SIMD) the C4 pass takes 1.00 instead of 1.43 ms
+#endif
+template <int Q> struct fe_waves { static constexpr int N = Q == 8 ? SBMBP_FE_WAVES_Q8 : 1; };  // register target (k_sweep_psi)
 template <int Q, bool EM>
-__global__ void __launch_bounds__(frame_cfg<Q>::TPB)
+__global__ void __launch_bounds__(frame_cfg<Q>::TPB) __attribute__((amdgpu_waves_per_eu(fe_waves<Q>::N)))
 k_fe_psi(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ nbr, const double *__restrict__ Mcur /* m^T */,
          const double *__restrict__ Mprev /* m^{T-1} */, const double *__restrict__ psi /* psi^T */,
          const uint32_t *__restrict__ blk_row, const uint32_t *__restrict__ blk_e0, const dev_params *__restrict__ P, int dc,
@@ -2597,16 +2601,34 @@ k_init_random(double *__restrict__ v, uint64_t n_vec, int Q, int ncomp, uint64_t
 // device initialisation: every out-message of a row starts as the row's (random) marginal, in both message buffers.
 // That state is consistent for the marginal-gather sweep without an explicit first sweep: the message l receives from i
 // IS psi_i, which is what the first sweep gathers (k_sweep_psi: first_from_psi).
-__global__ void __launch_bounds__(BLOCK)
-k_init_msgs_from_psi(const uint32_t *__restrict__ row_ptr, const double *__restrict__ psi, uint32_t n_rows, int Q,
-                     double *__restrict__ Ma, double *__restrict__ Mb) {
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n_rows) return;
-    double v[QMAX_RT], w[QMAX_RT];
-    for (int q = 0; q < Q; ++q) v[q] = psi[size_t(i) * Q + q];
-    encode_msg_rt(v, Q, w);
-    for (uint32_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k)
-        for (int q = 0; q < Q - 1; ++q) { Ma[size_t(k) * (Q - 1) + q] = w[q]; Mb[size_t(k) * (Q - 1) + q] = w[q]; }
+// On the sweep's segments, Q at compile time: a lane per directed edge (records written as the sweep writes them, consecutive
+// lanes consecutive records), the edge's row from the segment's row table. (Round 2 had a run-time-Q kernel - a lane per ROW
+// walking its edges, two Q-vectors in scratch memory -: 7.9 ms at C3 for 4.8 GB of records.)
+template <int Q>
+__global__ void __launch_bounds__(frame_cfg<Q>::TPB)
+k_init_msgs_from_psi_seg(const uint32_t *__restrict__ row_ptr, const double *__restrict__ psi, const uint32_t *__restrict__ blk_row,
+                         const uint32_t *__restrict__ blk_e0, double *__restrict__ Ma, double *__restrict__ Mb) {
+    constexpr int CAP = frame_cfg<Q>::CAP, RCAP = frame_cfg<Q>::RCAP, TPB = frame_cfg<Q>::TPB;
+    __shared__ uint16_t srow[CAP];
+    const int tid = threadIdx.x;
+    const uint32_t bid = blockIdx.x;
+    const uint32_t r0 = blk_row[bid], r1 = blk_row[bid + 1], e0 = blk_e0[bid];
+    const int nrows = int(r1 - r0), ne = int(blk_e0[bid + 1] - e0);
+    if (ne > CAP) {  // a hub row: one marginal for all its records
+        double v[Q];
+        load_vec<Q>(psi + size_t(r0) * Q, v);
+        for (int le = tid; le < ne; le += TPB) { store_msg<Q>(Ma, size_t(e0) + le, v); store_msg<Q>(Mb, size_t(e0) + le, v); }
+        return;
+    }
+    for (int r = tid; r < nrows && r < RCAP; r += TPB)
+        for (uint32_t e = row_ptr[r0 + r] - e0, ee = row_ptr[r0 + r + 1] - e0; e < ee; ++e) srow[e] = uint16_t(r);
+    __syncthreads();
+    for (int le = tid; le < ne; le += TPB) {
+        double v[Q];
+        load_vec<Q>(psi + size_t(r0 + srow[le]) * Q, v);
+        store_msg<Q>(Ma, size_t(e0) + le, v);
+        store_msg<Q>(Mb, size_t(e0) + le, v);
+    }
 }
 
 // host layout (Q components per message, sbmbp_set_state / sbmbp_get_state) <-> message records (Q-1 words)
