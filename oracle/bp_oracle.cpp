@@ -541,7 +541,12 @@ struct ar_t {
         const double m0 = mix(), d0 = damp();
         while (gl + 1 < NG) {
             ++gl;
-            if (mix() < m0 || damp() < d0) { reset_after(); trace("generic"); return; }
+            if (mix() < m0 || damp() < d0) {
+                // the first damped level starts from an unrelaxed field again: damping often steadies the field by itself, and a
+                // field level inherited from the undamped sweeps can make the damped ones crawl ((F) fires again if it must)
+                if (d0 == 1.0 && damp() < 1.0) fl = 0;
+                reset_after(); trace("generic"); return;
+            }
         }
         hold = 1 << 30;  // the ladder is used up: the run goes on as it is
     }

@@ -861,7 +861,13 @@ __device__ __forceinline__ void finalize_update(dev_params *__restrict__ P, cons
             const double m0 = cur_mix(), d0 = ar_gen_damp(gl);
             while (gl + 1 < AR_NG) {
                 ++gl;
-                if (cur_mix() < m0 || ar_gen_damp(gl) < d0) { reset_after(); return; }
+                if (cur_mix() < m0 || ar_gen_damp(gl) < d0) {
+                    // the first damped level starts from an unrelaxed field again: damping often steadies the field by itself, and
+                    // a field level inherited from the undamped sweeps can make the damped ones crawl ((F) fires again if it must)
+                    if (d0 == 1.0 && ar_gen_damp(gl) < 1.0) fl = 0;
+                    reset_after();
+                    return;
+                }
             }
             hold = 1 << 30;  // the ladder is used up: the run goes on as it is
         };

@@ -434,7 +434,11 @@ k_wfinalize(const double *__restrict__ partials, uint32_t n_part, int mode, dev_
                 const double m0 = cur_mix(), d0 = ar_gen_damp(gl);
                 while (gl + 1 < AR_NG) {
                     ++gl;
-                    if (cur_mix() < m0 || ar_gen_damp(gl) < d0) { reset_after(); return; }
+                    if (cur_mix() < m0 || ar_gen_damp(gl) < d0) {
+                        if (d0 == 1.0 && ar_gen_damp(gl) < 1.0) fl = 0;  // (finalize_update: the first damped level forgets the field level)
+                        reset_after();
+                        return;
+                    }
                 }
                 hold = 1 << 30;
             };
