@@ -144,6 +144,8 @@ def pmc_traffic(workload, kernel, n_gpus, E2, N, Q):
     sha = source_sha()
     stale = None
     stream_reads = E2 * (8.0 * (Q - 1) + 4.0) + N * 4.0  # own old message record (Q-1 components) + index per edge, row offsets
+    if Q > 16:  # k_wsweep: both records of an edge (own and reverse, Q components each) are contiguous runs of 8Q >= 136 bytes
+        stream_reads = E2 * (2 * 8.0 * Q + 4.0) + N * 4.0
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc*.json")), reverse=True):
         try:
             d = json.load(open(path))
@@ -154,7 +156,8 @@ def pmc_traffic(workload, kernel, n_gpus, E2, N, Q):
             if d.get("workload") != workload:
                 continue
             for k, e in d["kernels"].items():
-                if k.replace(" ", "").startswith(kernel.replace(">", ",").replace(" ", "")):
+                kk, want = k.replace(" ", ""), kernel.replace(" ", "")
+                if kk.startswith(want.replace(">", ",")) or kk.startswith(want):
                     c = e["counters"]
         elif d.get("kernel") == kernel and d.get("workload", "").startswith(workload + " "):  # round 1/2 files
             c = d["counters"]

@@ -13,7 +13,7 @@ python3 -c "from bench import source_sha; print(source_sha())" > $OUT/source_sha
 # (a gpurun call is limited to 20 minutes: PROFILE_PART=pmc runs the counter passes only, PROFILE_PART=rest everything else)
 PART=${PROFILE_PART:-all}
 if [ $PART != rest ]; then
-  for WL in C3 C4 C2 C5 Q64; do
+  for WL in C3 C4 C2 C5 Q32 Q64; do
     tools/pmc_workload.sh $R $WL > $OUT/pmc_$WL.log 2>&1 || echo "pmc $WL failed" >&2
   done
 fi
