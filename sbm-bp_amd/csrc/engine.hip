@@ -752,22 +752,32 @@ int site_edge_terms(sbmbp_engine *e, bool want_entropy, double out[4], double *d
     return fold_to_host(e, e->n_blk, FE_NP, FE_NP + 1, out);
 }
 
-// contraction <M_k, (m_0 x ... x m_{k-1}) M_k> of SURVEY A.4 on the host (Q^2k terms)
+// contraction <M_k, (m_0 x ... x m_{k-1}) M_k> of SURVEY A.4 on the host: the matrices are applied one tensor mode after the
+// other (k Q^(k+1) multiplications; summing all Q^2k terms directly took 0.1 s per call at Q = 64, k = 2 or Q = 16, k = 3 -
+// ten times the device side of the whole reduction pass). Mode j is digit j of the index, the least significant first.
 double contract(const double *Mk, uint32_t Q, unsigned k, const std::vector<const double *> &mats) {
     size_t T = 1;
     for (unsigned j = 0; j < k; ++j) T *= Q;
-    double acc = 0.0;
-    for (size_t a = 0; a < T; ++a) {
-        if (Mk[a] == 0.0) continue;
-        double row = 0.0;
-        for (size_t b = 0; b < T; ++b) {
-            double w = 1.0;
-            size_t ra = a, rb = b;
-            for (unsigned j = 0; j < k; ++j) { w *= mats[j][(ra % Q) * Q + (rb % Q)]; ra /= Q; rb /= Q; }
-            row += w * Mk[b];
-        }
-        acc += row * Mk[a];
+    std::vector<double> cur(Mk, Mk + T), nxt(T);
+    size_t stride = 1;
+    for (unsigned j = 0; j < k; ++j) {
+        const double *m = mats[j];
+        const size_t outer = T / (stride * Q);
+        for (size_t hi = 0; hi < outer; ++hi)
+            for (uint32_t a = 0; a < Q; ++a) {
+                double *dst = nxt.data() + (hi * Q + a) * stride;
+                for (size_t lo = 0; lo < stride; ++lo) dst[lo] = 0.0;
+                for (uint32_t b = 0; b < Q; ++b) {
+                    const double w = m[a * Q + b];
+                    const double *src = cur.data() + (hi * Q + b) * stride;
+                    for (size_t lo = 0; lo < stride; ++lo) dst[lo] += w * src[lo];
+                }
+            }
+        cur.swap(nxt);
+        stride *= Q;
     }
+    double acc = 0.0;
+    for (size_t a = 0; a < T; ++a) acc += Mk[a] * cur[a];
     return acc;
 }
 
