@@ -677,9 +677,15 @@ int fused_pass(sbmbp_engine *e, bool want_entropy, bool want_em) {
     if (e->wide) {  // Q > 16: k_wreduce (message-gather, matrix cores), hub rows included
         CHK(ensure_partials(e, size_t(std::max<uint32_t>(e->n_blk, 1)) * (WR_NP + 1)));
         CHK(ensure_small(e, WR_NP));
-        DISPATCH_QT(Q, hipLaunchKernelGGL((k_wreduce<QT>), dim3(e->n_blk), dim3(WTPB), 0, e->stream, e->d_row_ptr, e->d_rev, e->d_nbr,
-                                          e->d_M[e->cur], e->d_psi[e->pcur], e->d_blk_row, e->d_blk_e0, e->d_P, e->d_Pw, int(Q), int(e->dc),
-                                          int(want_entropy), adj_mode, d_w, e->d_partials));
+        if (want_entropy) {
+            DISPATCH_QT(Q, hipLaunchKernelGGL((k_wreduce<QT, true>), dim3(e->n_blk), dim3(WTPB), 0, e->stream, e->d_row_ptr, e->d_rev, e->d_nbr,
+                                              e->d_M[e->cur], e->d_psi[e->pcur], e->d_blk_row, e->d_blk_e0, e->d_P, e->d_Pw, int(Q), int(e->dc),
+                                              adj_mode, d_w, e->d_partials));
+        } else {
+            DISPATCH_QT(Q, hipLaunchKernelGGL((k_wreduce<QT, false>), dim3(e->n_blk), dim3(WTPB), 0, e->stream, e->d_row_ptr, e->d_rev, e->d_nbr,
+                                              e->d_M[e->cur], e->d_psi[e->pcur], e->d_blk_row, e->d_blk_e0, e->d_P, e->d_Pw, int(Q), int(e->dc),
+                                              adj_mode, d_w, e->d_partials));
+        }
         HIPCHK(hipGetLastError());
         double o6[WR_NP];
         CHK(fold_to_host(e, e->n_blk, WR_NP, WR_NP + 1, o6));

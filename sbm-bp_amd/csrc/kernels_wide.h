@@ -595,17 +595,19 @@ k_wrow_sums(const uint32_t *__restrict__ row_ptr, const double *__restrict__ psi
 // is walked once (its per-label products carried in registers of the first Q threads).
 // ------------------------------------------------------------------------------------------------
 constexpr int WR_NP = FE_NP + NE_NP;
-template <int QT>
-__global__ void __launch_bounds__(WTPB)
+// ENT: the entropy terms too (-m infer, compute_entropy). Without them (the free energy of an EM step) a third of the LDS and two of
+// the three matrix products per tile are not there: two workgroups per CU at Q = 64 instead of one.
+template <int QT, bool ENT>
+__global__ void __launch_bounds__(WTPB) __attribute__((amdgpu_waves_per_eu((!ENT && QT == 4) ? 2 : 1)))
 k_wreduce(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev, const uint32_t *__restrict__ nbr,
           const double *__restrict__ M, const double *__restrict__ psi, const uint32_t *__restrict__ blk_row,
           const uint32_t *__restrict__ blk_e0, const dev_params *__restrict__ P, const dev_wide *__restrict__ Pw, int Q, int dc,
-          int want_entropy, int adj_mode /* 0 none, 1 series weights, 2 exact */, const double *__restrict__ wmat, double *__restrict__ partials) {
+          int adj_mode /* 0 none, 1 series weights, 2 exact */, const double *__restrict__ wmat, double *__restrict__ partials) {
     constexpr int QP = 16 * QT, QS = 4 * QT;
     __shared__ double sb[WCAP * QP];
-    __shared__ double sc[WCAP * QP];
-    __shared__ double sV[3 * WRCAP * QP];  // per row: w^T psi_i, cab^T psi_i, (cab log cab)^T psi_i
-    __shared__ double sL[2 * WRCAP * QP];  // per row: log weights of the site term / of the entropy site term
+    __shared__ double sc[ENT ? WCAP * QP : 1];
+    __shared__ double sV[(ENT ? 3 : 1) * WRCAP * QP];  // per row: w^T psi_i, cab^T psi_i, (cab log cab)^T psi_i
+    __shared__ double sL[(ENT ? 2 : 1) * WRCAP * QP];  // per row: log weights of the site term / of the entropy site term
     __shared__ uint32_t srp[WRCAP + 1];
     __shared__ uint16_t srow[WCAP];
     __shared__ double sred[(WTPB / 64) * (WR_NP + 1)];
@@ -628,12 +630,14 @@ k_wreduce(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev
                 for (int a = 0; a < Q; ++a) {
                     const double p = pi[a];
                     v += wmat[a * Q + q] * p;
-                    if (want_entropy) { vc += Pw->cab[a * Q + q] * p; vu += Pw->cab[a * Q + q] * Pw->logcab[a * Q + q] * p; }
+                    if (ENT) { vc += Pw->cab[a * Q + q] * p; vu += Pw->cab[a * Q + q] * Pw->logcab[a * Q + q] * p; }
                 }
             }
             sV[r * QP + q] = v;
-            sV[(WRCAP + r) * QP + q] = vc;
-            sV[(2 * WRCAP + r) * QP + q] = vu;
+            if (ENT) {
+                sV[(ENT ? WRCAP + r : 0) * QP + q] = vc;
+                sV[(ENT ? 2 * WRCAP + r : 0) * QP + q] = vu;
+            }
         }
     };
     // the 16 edges [base, base + 16) of this wave: fields to LDS slot `slot0 + le_t`, edge and adjacent-pair terms to acc
@@ -651,7 +655,7 @@ k_wreduce(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev
         for (int s = 0; s < QS; ++s) t1[s] = b[s] * mo[s];
         const double nl = edge_sum<QS>(t1);
         if (valid && g == 0) acc[1] += log(nl);
-        if (want_entropy) {  // uniform
+        if (ENT) {  // uniform
             wide_matvec<QT>(Pw->tC, mi, c);
             wide_matvec<QT>(Pw->tCL, mi, cl);
 #pragma unroll
@@ -666,7 +670,7 @@ k_wreduce(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev
 #pragma unroll
             for (int s = 0; s < QS; ++s) {
                 sb[(slot0 + le_t) * QP + g + 4 * s] = b[s];
-                if (want_entropy) sc[(slot0 + le_t) * QP + g + 4 * s] = c[s];
+                if (ENT) sc[ENT ? (slot0 + le_t) * QP + g + 4 * s : 0] = c[s];
             }
         }
         if (adj_mode) {  // uniform
@@ -678,22 +682,22 @@ k_wreduce(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev
             for (int s = 0; s < QS; ++s) { const int t = g + 4 * s; t1[s] = t < Q ? sV[r * QP + t] * pl[s] : 0.0; }
             const double y = edge_sum<QS>(t1);
             double yc = 0.0, u = 0.0;
-            if (want_entropy) {
+            if (ENT) {
 #pragma unroll
-                for (int s = 0; s < QS; ++s) { const int t = g + 4 * s; t1[s] = t < Q ? sV[(WRCAP + r) * QP + t] * pl[s] : 0.0; }
+                for (int s = 0; s < QS; ++s) { const int t = g + 4 * s; t1[s] = t < Q ? sV[(ENT ? WRCAP + r : 0) * QP + t] * pl[s] : 0.0; }
                 yc = edge_sum<QS>(t1);
 #pragma unroll
-                for (int s = 0; s < QS; ++s) { const int t = g + 4 * s; t1[s] = t < Q ? sV[(2 * WRCAP + r) * QP + t] * pl[s] : 0.0; }
+                for (int s = 0; s < QS; ++s) { const int t = g + 4 * s; t1[s] = t < Q ? sV[(ENT ? 2 * WRCAP + r : 0) * QP + t] * pl[s] : 0.0; }
                 u = edge_sum<QS>(t1);
             }
             if (valid && g == 0) {
                 const double num = u * invN, den = 1.0 - yc * invN;
                 if (adj_mode == 1) {
                     acc[FE_NP] += log1p(-y * invN);
-                    if (want_entropy) acc[FE_NP + 1] += num / den;
+                    if (ENT) acc[FE_NP + 1] += num / den;
                 } else {
                     if (y != 0.0) acc[FE_NP] += log(y);
-                    if (want_entropy && num * den != 0.0) acc[FE_NP + 1] += num / den;
+                    if (ENT && num * den != 0.0) acc[FE_NP + 1] += num / den;
                 }
             }
         }
@@ -709,13 +713,13 @@ k_wreduce(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
         if (j == 0) acc[0] += mx + log(sum);  // log Z_i  (bp.cpp:446-502)
-        if (want_entropy) {  // e_site (bp.cpp:506-560): sum_q w_q (-h_q/N) / sum_q w_q
+        if (ENT) {  // e_site (bp.cpp:506-560): sum_q w_q (-h_q/N) / sum_q w_q
             double me = -1.0e300;
-            for (int q = j; q < Q; q += 16) me = fmax(me, sL[(WRCAP + r) * QP + q]);
+            for (int q = j; q < Q; q += 16) me = fmax(me, sL[(ENT ? WRCAP + r : 0) * QP + q]);
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) me = fmax(me, __shfl_xor(me, o, 16));
             double num = 0.0, den = 0.0;
-            for (int q = j; q < Q; q += 16) { const double w = exp(sL[(WRCAP + r) * QP + q] - me); den += w; num += w * (-Pw->hN[q]); }
+            for (int q = j; q < Q; q += 16) { const double w = exp(sL[(ENT ? WRCAP + r : 0) * QP + q] - me); den += w; num += w * (-Pw->hN[q]); }
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) { num += __shfl_xor(num, o, 16); den += __shfl_xor(den, o, 16); }
             if (j == 0) acc[2] += num / den;
@@ -740,12 +744,12 @@ k_wreduce(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev
             int ex = 0, cx = 0;
             for (int e = es; e < ee; ++e) {
                 a *= sb[e * QP + q];
-                if (want_entropy) cc *= sc[e * QP + q];
-                if (((e - es) & 3) == 3) { int kx; a = frexp(a, &kx); ex += kx; if (want_entropy) { cc = frexp(cc, &kx); cx += kx; } }
+                if (ENT) cc *= sc[ENT ? e * QP + q : 0];
+                if (((e - es) & 3) == 3) { int kx; a = frexp(a, &kx); ex += kx; if (ENT) { cc = frexp(cc, &kx); cx += kx; } }
             }
             const double fld = dc ? double(ee - es) : beta;
             sL[r * QP + q] = log(a) + double(ex) * 0.6931471805599453 + Pw->logeta[q] - fld * Pw->hN[q];
-            if (want_entropy) sL[(WRCAP + r) * QP + q] = log(cc) + double(cx) * 0.6931471805599453 + Pw->logeta[q] - Pw->hN[q];
+            if (ENT) sL[(ENT ? WRCAP + r : 0) * QP + q] = log(cc) + double(cx) * 0.6931471805599453 + Pw->logeta[q] - Pw->hN[q];
         }
         __syncthreads();
         {
@@ -764,14 +768,14 @@ k_wreduce(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rev
                 const int cnt = min(WCAP, ne - c0);
                 for (int e = 0; e < cnt; ++e) {
                     a *= sb[e * QP + tid];
-                    if (want_entropy) cc *= sc[e * QP + tid];
-                    if ((e & 3) == 3) { int kx; a = frexp(a, &kx); ex += kx; if (want_entropy) { cc = frexp(cc, &kx); cx += kx; } }
+                    if (ENT) cc *= sc[ENT ? e * QP + tid : 0];
+                    if ((e & 3) == 3) { int kx; a = frexp(a, &kx); ex += kx; if (ENT) { cc = frexp(cc, &kx); cx += kx; } }
                 }
             }
         }
         if (tid < Q) {
             sL[tid] = log(a) + double(ex) * 0.6931471805599453 + Pw->logeta[tid] - (dc ? double(ne) : beta) * Pw->hN[tid];
-            if (want_entropy) sL[WRCAP * QP + tid] = log(cc) + double(cx) * 0.6931471805599453 + Pw->logeta[tid] - Pw->hN[tid];
+            if (ENT) sL[(ENT ? WRCAP : 0) * QP + tid] = log(cc) + double(cx) * 0.6931471805599453 + Pw->logeta[tid] - Pw->hN[tid];
         }
         __syncthreads();
         if (tid < 16) site_terms(0, double(ne), tid);
