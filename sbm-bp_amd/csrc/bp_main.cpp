@@ -517,9 +517,14 @@ int main(int argc, char const *argv[]) {
         sbmbp_stats st;
         sbmbp_get_stats(eng, &st);
         std::ofstream mj(var_map.get("metrics_json")[0].c_str());
+        // where the adaptive relaxation of the synchronous schedule ended: [0, -1, mix, 1] = plain sweeps
+        int ar_f = 0, ar_g = -1;
+        double ar_mix = 1.0, ar_damp = 1.0;
+        (void)sbmbp_get_relaxation(eng, &ar_f, &ar_g, &ar_mix, &ar_damp);
         mj << std::setprecision(12) << "{\"sweeps\":" << st.sweeps << ",\"edge_msg_updates\":" << st.edge_msg_updates
            << ",\"marginal_gather_sweeps\":" << st.psi_form_sweeps << ",\"run_seconds\":" << secs
-           << ",\"bytes_per_sweep\":" << st.bytes_per_sweep << ",\"device_bytes\":" << st.device_bytes << "}\n";
+           << ",\"bytes_per_sweep\":" << st.bytes_per_sweep << ",\"device_bytes\":" << st.device_bytes
+           << ",\"relaxation\":[" << ar_f << "," << ar_g << "," << ar_mix << "," << ar_damp << "]}\n";
     }
     sbmbp_destroy(eng);
     sbmbp_graph_destroy(graph);

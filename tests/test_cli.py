@@ -115,6 +115,7 @@ def test_matched_parameters_precision_and_marginals(tmp_path):
     assert err.count("margEntropy H(v) is") == 1000  # per-node entropies on clog (bp.cpp:95-97)
     m = json.load(open(mj))
     assert m["sweeps"] == int(niter) + 1 and m["marginal_gather_sweeps"] == m["sweeps"] - 1
+    assert m["relaxation"][:2] == [0, -1]  # plain synchronous sweeps: the adaptive relaxation never stepped in
 
 
 @pytest.mark.gpu
@@ -130,17 +131,20 @@ def test_degree_corrected_run_prints_minus_nan_entropy():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("gpus", [[], ["--gpus", 3]])
-def test_reference_flags_only_converge_on_the_oscillating_hub_instance(gpus):
+def test_reference_flags_only_converge_on_the_oscillating_hub_instance(gpus, tmp_path):
     """plain SBM on a power-law graph (fixture hub_dc0_tight_seed0: the reference converges after 139 sweeps): with nothing but
     the reference's own flags bin/bp prints the reference's line - free energy, entropy and overlap to 1e-9, niter of the same
     size - on one GPU and sharded. (Round 2 printed niter = -1 here: plain synchronous sweeps oscillate.)"""
     g = golden("hub_dc0_tight_seed0")["result"]
     rc, out, err = run("-l", gpath("hub_n600.edgelist"), "-n", 200, 200, 200, "--pa", 0.3333333333333333, 0.3333333333333333,
                        0.3333333333333333, "--cab", 9, 1.5, 1.5, 9, 1.5, 9, "-t", 2000, "-e", 1e-12, "-m", "infer", "-d", 0,
-                       "--precision", 15, *gpus)
+                       "--precision", 15, "--metrics_json", tmp_path / "m.json", *gpus)
     assert rc == 0, err
     e, f, ov, niter = out.split("\n")[0].split()
     assert abs(int(niter) - g["niter"]) <= 10  # reference 139, synchronous with the field relaxed on the device 142
+    if not gpus:  # the metrics say what the device did about the oscillation: field level 1 (field_mix 0.25), no damping
+        m = json.load(open(tmp_path / "m.json"))
+        assert m["relaxation"][:2] == [1, -1] and m["relaxation"][2] == 0.25 and m["relaxation"][3] == 1.0
     assert abs(float(f) - g["f"]) < 1e-9 and abs(float(e) - g["e"]) < 1e-8 and abs(float(ov) - g["overlap"]) < 1e-9
 
 
