@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -120,8 +121,22 @@ std::vector<u64> chunk_rows(const u64 *rp, u64 lo, u64 n, u32 n_chunks) {  // lo
     return cuts;
 }
 
+// SBMBP_HOST_TIMING=1: phases of the plan on stderr (rank 0 only; measurement aid)
+struct plan_timer {
+    bool on;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    explicit plan_timer(int rank) : on(rank == 0 && std::getenv("SBMBP_HOST_TIMING") != nullptr) {}
+    void lap(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[sbmbp plan] %-26s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 int build_plan(const sbmbp_graph &g, int world, int rank, u32 n_chunks, shard_plan &P) {
     const u64 N = g.n;
+    plan_timer tm(rank);
     if (world < 1 || rank < 0 || rank >= world) { set_error("rank outside the communicator"); return SBMBP_ERR_ARG; }
     if (N < u64(world)) { set_error("fewer vertices than shards"); return SBMBP_ERR_ARG; }
     const u64 *rp = g.row_ptr.data();
@@ -156,6 +171,7 @@ int build_plan(const sbmbp_graph &g, int world, int rank, u32 n_chunks, shard_pl
     std::vector<u32> remote;
     for (u64 v = 0; v < N; ++v) if (hmap[v] == 0) { hmap[v] = u32(remote.size()); remote.push_back(u32(v)); }
     P.n_halo = u32(remote.size());
+    tm.lap("halo vertices");
     P.recv_counts.assign(W, 0);
     std::vector<u64> halo_off(W + 1, 0);
     for (u32 x = 0; x < P.n_halo; ++x) P.recv_counts[owner_of(remote[x])]++;
@@ -191,19 +207,21 @@ int build_plan(const sbmbp_graph &g, int world, int rank, u32 n_chunks, shard_pl
         const u64 l = nb[k];
         P.nbr_local[k] = (l >= lo && l < hi) ? u32(l - lo) : P.n_own + renamed[hmap[l]];
     }
+    tm.lap("local neighbour ids");
     // send lists: my rows with a neighbour owned by p, ascending, per peer
     std::vector<std::vector<u32>> rows_p(W);
     std::vector<std::vector<u32>> cut_edges(W);  // my cut edges per peer, in my edge order (row, neighbour)
     for (u32 i = 0; i < P.n_own; ++i) {
-        int last = -1;
+        int last = -1, o = 0;
         for (u64 k = P.row_ptr[i]; k < P.row_ptr[i + 1]; ++k) {
             const u64 l = nb[k];
             if (l >= lo && l < hi) continue;
-            const int o = owner_of(l);
+            while (l >= P.bounds[size_t(o) + 1]) ++o;  // neighbours ascend within a row, so owners do: no search per edge
             cut_edges[o].push_back(u32(k));
-            if (o != last) { rows_p[o].push_back(i); last = o; }  // neighbours ascend, so owners do
+            if (o != last) { rows_p[o].push_back(i); last = o; }
         }
     }
+    tm.lap("cut edges per peer");
     P.send_counts.assign(W, 0);
     P.send_counts_cp.assign(size_t(Cn) * W, 0);
     std::vector<std::vector<u64>> cutp(W, std::vector<u64>(Cn + 1, 0));
@@ -219,6 +237,7 @@ int build_plan(const sbmbp_graph &g, int world, int rank, u32 n_chunks, shard_pl
             P.send_idx_chunked.insert(P.send_idx_chunked.end(), rows_p[p].begin() + cutp[p][c], rows_p[p].begin() + cutp[p][c + 1]);
         P.send_off_c[c + 1] = P.send_idx_chunked.size();
     }
+    tm.lap("send lists");
     // send slots of every own row (where the sweep kernel drops a fresh marginal for its readers)
     P.snd_ptr.assign(size_t(P.n_own) + 1, 0);
     for (u32 row : P.send_idx_chunked) P.snd_ptr[row + 1]++;
@@ -228,6 +247,7 @@ int build_plan(const sbmbp_graph &g, int world, int rank, u32 n_chunks, shard_pl
         std::vector<u32> fill(P.snd_ptr.begin(), P.snd_ptr.end() - 1);
         for (u32 s = 0; s < P.send_idx_chunked.size(); ++s) P.snd_slot[fill[P.send_idx_chunked[s]]++] = s;
     }
+    tm.lap("send slots");
     // cut edges: what I receive for peer p sits behind my own records in MY edge order; what I send to p is ordered as p's
     // edge order, i.e. by (neighbour, row)
     P.msg_counts.assign(W, 0);
@@ -242,15 +262,26 @@ int build_plan(const sbmbp_graph &g, int world, int rank, u32 n_chunks, shard_pl
         P.msg_counts[p] = cut_edges[p].size();
         for (u64 x = 0; x < cut_edges[p].size(); ++x) P.rev_local[cut_edges[p][x]] = u32(P.n_edges + off + x);
         off += cut_edges[p].size();
-        std::vector<u32> ord(cut_edges[p]);
-        std::stable_sort(ord.begin(), ord.end(), [&](u32 a, u32 b) { return nb[a] < nb[b]; });
-        P.msg_send_edge.insert(P.msg_send_edge.end(), ord.begin(), ord.end());
+        // the peer's edge order is (neighbour, row): a stable counting sort of my (row, neighbour)-ordered cut edges by the
+        // neighbour's offset in the peer's row range (a comparison sort through nb[] took most of the plan's time)
+        const std::vector<u32> &ce = cut_edges[p];
+        if (!ce.empty()) {
+            const u64 plo = P.bounds[p], pn = P.bounds[p + 1] - plo;
+            std::vector<u32> cnt(size_t(pn) + 1, 0);
+            for (u32 a : ce) cnt[size_t(nb[a] - plo) + 1]++;
+            for (u64 v = 0; v < pn; ++v) cnt[v + 1] += cnt[v];
+            const size_t base = P.msg_send_edge.size();
+            P.msg_send_edge.resize(base + ce.size());
+            for (u32 a : ce) P.msg_send_edge[base + cnt[size_t(nb[a] - plo)]++] = a;
+        }
     }
+    tm.lap("cut-edge records");
     P.n_halo_msgs = off;
     if (P.n_edges + P.n_halo_msgs >= (u64(1) << 32)) { set_error("a shard's message buffer exceeds 2^32 records"); return SBMBP_ERR_UNSUPPORTED; }
     P.table_deg.resize(size_t(P.n_own) + P.n_halo);
     for (u32 i = 0; i < P.n_own; ++i) P.table_deg[i] = u32(rp[lo + i + 1] - rp[lo + i]);
     for (u32 x = 0; x < P.n_halo; ++x) { const u64 v = P.halo_global[x]; P.table_deg[P.n_own + x] = u32(rp[v + 1] - rp[v]); }
+    tm.lap("table degrees");
     return SBMBP_OK;
 }
 
