@@ -399,7 +399,7 @@ def main():
             # 1.5 - 2.8 ms for every other variant: a high-priority stream of one process starves the low-priority streams of
             # the others while all of them wait for each other in the per-sweep collective. SBMBP_SHARD_PRIO=1 still exists as
             # an opt-in for a node where every rank has its GPU to itself.)
-            # (a plan costs 3 s per rank at 8 ranks of C3 and 12 s at 2 ranks: five candidates)
+            # (five candidates; a plan of the C3 graph is built in well under a second per rank at 8 ranks, a few seconds at 2)
             pinned_streams = os.environ.get("SBMBP_SHARD_STREAMS")
             variants = [1, 2, 4, 8] + ([] if pinned_streams else ["4s"])
             # two plans resident at once (the best so far and the candidate): at the capacity workloads the old best is
